@@ -1,0 +1,173 @@
+"""Pins the oracle at flow level (CPU only): the composition rules of
+cnf_ot/models/{flows,autoregressive,conditional}.py, the committed golden
+vectors, the two independent restatements against each other, and the loss
+restatement's closed forms."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import losses as ol
+from oracle.numpy_flow import NumpyFlow
+
+CFGS = {
+  "flow_d1.npz": oracle.OracleConfig(D=1),
+  "flow_d2.npz": oracle.OracleConfig(D=2),
+  "flow_d2_wild.npz": oracle.OracleConfig(D=2),
+  "flow_d10.npz": oracle.OracleConfig(D=10),
+  "flow_d3_k8_h32_m3_l3.npz": oracle.OracleConfig(D=3, L=3, H=32, M=3, K=8),
+}
+
+
+def test_param_counts(oracle_lib):
+  # SURVEY.md 3.1 / BASELINE.md: 1 200 at D=2, 11 824 at D=10
+  assert oracle_lib.param_count(oracle.OracleConfig(D=2)) == 1200
+  assert oracle_lib.param_count(oracle.OracleConfig(D=10)) == 11824
+  assert oracle_lib.param_count(oracle.OracleConfig(D=1)) == 16
+
+
+@pytest.mark.parametrize("name", sorted(CFGS))
+def test_golden_vectors(oracle_lib, golden_dir, name):
+  cfg = CFGS[name]
+  g = np.load(os.path.join(golden_dir, name))
+  assert list(g["cfg"]) == [cfg.D, cfg.L, cfg.H, cfg.M, cfg.K]
+  for tag, c in (("u", g["c_uniform"]), ("p", g["c_per"])):
+    y, fldj = oracle_lib.forward_logdet(cfg, g["params"], g["noise"], c)
+    assert np.array_equal(y, g[f"y_{tag}"]) or np.abs(y - g[f"y_{tag}"]).max() < 1e-13
+    assert np.abs(fldj - g[f"fldj_{tag}"]).max() < 1e-12
+    _, lp = oracle_lib.sample_logprob(cfg, g["params"], g["noise"], c)
+    assert np.abs(lp - g[f"lp_sample_{tag}"]).max() < 1e-12
+    xb, ildj = oracle_lib.inverse_logdet(cfg, g["params"], g[f"y_{tag}"], c)
+    assert np.abs(xb - g[f"x_back_{tag}"]).max() < 1e-12
+    assert np.abs(ildj - g[f"ildj_{tag}"]).max() < 1e-12
+  lpv = oracle_lib.log_prob(cfg, g["params"], g["value"], g["c_uniform"])
+  assert np.abs(lpv - g["lp_value_u"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("name", sorted(CFGS))
+def test_flow_roundtrip_and_logprob_consistency(oracle_lib, golden_dir, name):
+  """inverse(forward(x,c),c) == x, logdets antisymmetric, and
+  log_prob(sample) == the log_prob returned with the sample
+  (conditional.py:316-321 vs :399-402)."""
+  g = np.load(os.path.join(golden_dir, name))
+  # the scale-0.5 `wild` set is ill-conditioned (local slopes up to e^16): even
+  # float64 only round-trips it to ~1e-8
+  tol = 1e-10 if float(g["scale"]) < 0.5 or "d1" in name else 1e-6
+  for tag in ("u", "p"):
+    assert np.abs(g[f"x_back_{tag}"] - g["noise"]).max() < tol
+    assert np.abs(g[f"ildj_{tag}"] + g[f"fldj_{tag}"]).max() < tol
+    assert np.abs(g[f"lp_{tag}"] - g[f"lp_sample_{tag}"]).max() < tol
+
+
+@pytest.mark.parametrize("name", sorted(CFGS))
+def test_numpy_restatement_agrees_with_c(oracle_lib, golden_dir, name):
+  cfg = CFGS[name]
+  g = np.load(os.path.join(golden_dir, name))
+  flow = NumpyFlow(g["params"], D=cfg.D, L=cfg.L, H=cfg.H, M=cfg.M, K=cfg.K)
+  for tag, c in (("u", g["c_uniform"]), ("p", g["c_per"])):
+    y, lp = flow.sample_logprob(g["noise"], c)
+    assert np.abs(y - g[f"y_{tag}"]).max() < 1e-11
+    assert np.abs(lp - g[f"lp_sample_{tag}"]).max() < 1e-11
+  lpv = flow.log_prob(g["value"], g["c_uniform"])
+  assert np.abs(lpv - g["lp_value_u"]).max() < 1e-11
+
+
+def test_identity_at_init(oracle_lib):
+  """flows.py:48,71-76 => flow is the identity on [-10,10]: log_prob is the
+  standard-normal log-pdf and sample returns the base noise."""
+  for D in (1, 2, 10):
+    cfg = oracle.OracleConfig(D=D)
+    params = np.zeros(oracle_lib.param_count(cfg))
+    rng = np.random.default_rng(D)
+    x = rng.normal(size=(300, D)) * 3
+    y, lp = oracle_lib.sample_logprob(cfg, params, x, [0.3])
+    assert np.abs(y - x).max() < 1e-13
+    ref = (-0.5 * x * x - 0.5 * np.log(2 * np.pi)).sum(1)
+    assert np.abs(lp - ref).max() < 1e-12
+    assert np.abs(oracle_lib.log_prob(cfg, params, x, [0.9]) - ref).max() < 1e-12
+
+
+def test_logdet_matches_fd_jacobian(oracle_lib, golden_dir):
+  """sum of per-dimension logdets == log|det| of the full D x D Jacobian of the
+  flow map (the flow-level form of tests/test_rqs_accuracy.py:105-133)."""
+  cfg = oracle.OracleConfig(D=3, L=3, H=32, M=3, K=8)
+  g = np.load(os.path.join(golden_dir, "flow_d3_k8_h32_m3_l3.npz"))
+  x0 = g["noise"][10:20]
+  h = 1e-5
+  _, fldj = oracle_lib.forward_logdet(cfg, g["params"], x0, g["c_uniform"])
+  J = np.zeros((x0.shape[0], 3, 3))
+  for j in range(3):
+    e = np.zeros(3); e[j] = h
+    yp, _ = oracle_lib.forward_logdet(cfg, g["params"], x0 + e, g["c_uniform"])
+    ym, _ = oracle_lib.forward_logdet(cfg, g["params"], x0 - e, g["c_uniform"])
+    J[:, :, j] = (yp - ym) / (2 * h)
+  assert np.abs(np.log(np.abs(np.linalg.det(J))) - fldj).max() < 1e-7
+
+
+def test_first_spline_ignores_c_and_is_shared(oracle_lib):
+  """Appendix B quirk: the d=0 spline of EVERY layer uses the shared `first`
+  parameters and ignores c (flows.py:47-55, autoregressive.py:88-92)."""
+  cfg = oracle.OracleConfig(D=1, L=3)
+  rng = np.random.default_rng(0)
+  first = rng.normal(size=16)
+  x = rng.normal(size=(50, 1)) * 2
+  y_a, ld_a = oracle_lib.forward_logdet(cfg, first, x, [0.1])
+  y_b, ld_b = oracle_lib.forward_logdet(cfg, first, x, [0.9])
+  assert np.array_equal(y_a, y_b) and np.array_equal(ld_a, ld_b)
+  # three applications of the same scalar spline inverse
+  v, tot = x[:, 0].copy(), np.zeros(50)
+  for _ in range(3):
+    v, ld = oracle_lib.rqs(np.tile(first, (50, 1)), v, 5, -10.0, 10.0, 1e-4, inverse=True)
+    tot += ld
+  assert np.abs(v - y_a[:, 0]).max() < 1e-13 and np.abs(tot - ld_a).max() < 1e-13
+
+
+def test_philox_known_answer(oracle_lib):
+  """Random123 known-answer vectors for philox4x32-10."""
+  import ctypes
+  lib = oracle_lib.load_library()
+  def run(ctr, key):
+    c = (ctypes.c_uint32 * 4)(*ctr); k = (ctypes.c_uint32 * 2)(*key); o = (ctypes.c_uint32 * 4)()
+    lib.cnf_oracle_philox4x32(c, k, o)
+    return [int(v) for v in o]
+  assert run([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+  assert run([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+  assert run([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+    [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_philox_normals_are_standard_and_offset_consistent(oracle_lib):
+  z = oracle_lib.normal(42, 0, 200000)
+  assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+  assert abs((z ** 4).mean() - 3) < 0.1
+  # the stream is a function of the element index only
+  assert np.array_equal(oracle_lib.normal(42, 1001, 50), z[1001:1051])
+  assert not np.array_equal(oracle_lib.normal(43, 0, 50), z[:50])
+
+
+# ---- loss restatement: closed forms at the identity flow ---------------------
+
+def _identity_flow(D):
+  cfg = oracle.OracleConfig(D=D)
+  return ol.OracleFlow(cfg, np.zeros(oracle.param_count(cfg)))
+
+
+def test_losses_at_identity_flow(oracle_lib):
+  D, B = 2, 4096
+  flow = _identity_flow(D)
+  z = oracle_lib.normal(1, 0, B * D).reshape(B, D)
+  # identity flow does not depend on c => zero velocity; score of N(0,I) is -r
+  assert ol.kinetic_loss_fn(flow, D, 0.01, 0.5, z) == 0.0
+  ks = ol.kinetic_with_score_loss_fn(flow, D, 2.0, 0.01, 0.01, 0.5, z)
+  assert abs(ks - ((z / 2.0) ** 2).mean() * D / 2) < 1e-8
+  assert abs(ol.potential_loss_fn(flow, 0, "quadratic", 1.0, z) - (z ** 2).sum(1).mean() / 2) < 1e-12
+  # reverse KL at c=0 against N(0, 2/beta*(T+1) I) with beta=4, T=1 => var 1 => 0
+  assert abs(ol.reverse_kl_loss_fn(flow, 1.0, 4.0, 0.0, z)) < 1e-12
+  # flow matching, OU drift: v = -sigma*r, truth = -a*r
+  fm = ol.flow_matching_loss_fn(flow, D, 1.0, 0.5, "ou", 0.5, z)
+  assert abs(fm - ((0.5 * z) ** 2).mean() * D / 2) < 1e-7
+  # kl: samples = z + centre*(T-c)/T; at c=T samples = z
+  comp = np.arange(B) % 8
+  kl_T = ol.kl_loss_fn(flow, 1.0, 1.0, z, "mixture", comp)
+  assert abs(kl_T - (0.5 * (z ** 2).sum(1) + np.log(2 * np.pi)).mean()) < 1e-12
