@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X.
+
+metric : MC samples/sec through flow fwd + log|det J| (sample_and_log_prob,
+         the reference's conditional.py:353-402) at dim=2, batch=65536.
+step   : one pass of the hot path over one batch of 65 536 synthetic base-noise
+         samples (config 2 of BASELINE.json: OT free, dim=2) with its own
+         condition t; inputs resident in HBM before the timed region; outputs
+         y[65536,2] and log_prob[65536] written to HBM for every step.
+launch : steps are issued as fused multi-slice launches (`--slices-per-launch`
+         steps per launch, each slice with its own c) -- the shape of the
+         reference's evaluator cnf_ot/utils.py:311-340 (10 000 slices x 65 536);
+         `per_call` in the JSON line is the same work issued one launch per step.
+N GPUs : one process per GPU (torch.distributed, backend nccl = RCCL); every
+         step's batch is sample-sharded in contiguous blocks of 65536/N
+         (SURVEY.md 8e); no data-path collective; total work fixed => "strong".
+
+  python bench.py --gpus 1 --steps 4096 --warmup 256
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+METRIC = "MC samples/sec through flow fwd+log|detJ| at dim=2, batch=65536"
+DIM = 2
+BATCH = 65536
+# algorithmic work per sample per flow pass, fp32, default net
+FLOP_PER_SAMPLE = 2176 + 400          # conditioner MLP + splines
+BYTES_PER_SAMPLE = 4 * (2 * DIM + 1)  # x in, y out, log_prob out (c is per slice)
+PEAK_FP32_TFLOPS = 157.3              # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=4096)
+  ap.add_argument("--warmup", type=int, default=256)
+  ap.add_argument("--slices-per-launch", type=int, default=256)
+  ap.add_argument("--param-scale", type=float, default=0.2)
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--cpu-seconds", type=float, default=12.0)
+  ap.add_argument("--no-per-call", action="store_true")
+  return ap.parse_args()
+
+
+def cpu_baseline(params64, seconds):
+  """The oracle (float64 C restatement, OpenMP over the host cores) timed on a
+  bounded sample of the same workload.  A reported baseline, not the target."""
+  import oracle
+  ocfg = oracle.OracleConfig(D=DIM)
+  oracle.build_library()
+  rng = np.random.default_rng(0)
+  noise = rng.normal(size=(BATCH, DIM))
+  oracle.sample_logprob(ocfg, params64, noise, [0.5])          # warm-up
+  t0 = time.perf_counter()
+  n = 0
+  while True:
+    oracle.sample_logprob(ocfg, params64, noise, [n / 64.0 % 1.0])
+    n += 1
+    dt = time.perf_counter() - t0
+    if dt >= seconds or n >= 4096:
+      break
+  return {
+    "value": n * BATCH / dt, "unit": "samples/s", "cores": oracle.num_threads(),
+    "kind": "port",
+    "sample": f"{n} batches of {BATCH} (float64 C oracle, OpenMP, {dt:.1f} s)",
+  }
+
+
+def main():
+  args = parse_args()
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    args.gpus = world
+  assert torch.cuda.is_available(), "bench.py needs an MI355X (ROCm) device"
+  dev = torch.device("cuda", local_rank)
+  torch.cuda.set_device(dev)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("nccl", device_id=dev)
+
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+
+  if BATCH % world != 0 or (BATCH // world) % 256 != 0:
+    raise SystemExit(f"batch {BATCH} does not shard into 256-sample tiles over {world} GPUs")
+  b_local = BATCH // world
+  S = max(1, min(args.slices_per_launch, args.steps))
+
+  cfg = FlowConfig(dim=DIM)
+  params = Params.random(cfg, args.param_scale, seed=42, device=dev)
+  eng = FlowEngine(cfg, dev).load(params)
+
+  # synthetic inputs, resident in HBM: S distinct slices; slice s of this rank is
+  # samples [s*BATCH + rank*b_local, +b_local) of the seed-42 Philox stream
+  noise = torch.empty(S, b_local, DIM, device=dev)
+  for s in range(S):
+    noise[s] = eng.normal(42, b_local, first_sample=s * BATCH + rank * b_local)
+  t_slices = torch.linspace(0.0, 1.0, S, device=dev)
+  y = torch.empty(S * b_local, DIM, device=dev)
+  lp = torch.empty(S * b_local, device=dev)
+  noise_flat = noise.view(S * b_local, DIM)
+
+  def run(n_steps, events=None):
+    done = 0
+    while done < n_steps:
+      s = min(S, n_steps - done)
+      if events is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+      eng.sample_logprob(noise_flat[:s * b_local], t_slices[:s], out=y[:s * b_local], logp_out=lp[:s * b_local])
+      if events is not None:
+        e1.record()
+        events.append((e0, e1, s))
+      done += s
+
+  def barrier():
+    torch.cuda.synchronize()
+    if dist is not None:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  run(max(args.warmup, 1) if args.warmup > 0 else 0)
+  barrier()
+  events = []
+  t0 = time.perf_counter()
+  run(args.steps, events)
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  if dist is not None:
+    dist.barrier()
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  assert torch.isfinite(lp).all(), "non-finite log_prob in the bench output"
+
+  # dominant kernel: average launch duration from HIP events on the launch stream
+  full = [(a.elapsed_time(b) * 1e-3, s) for a, b, s in events if s == S] or \
+         [(a.elapsed_time(b) * 1e-3, s) for a, b, s in events]
+  k_dur = sum(d for d, _ in full) / len(full)
+  k_samples = full[0][1] * b_local
+  achieved_tflops = FLOP_PER_SAMPLE * k_samples / k_dur / 1e12
+  achieved_gbs = BYTES_PER_SAMPLE * k_samples / k_dur / 1e9
+
+  value = args.steps * BATCH / elapsed
+  line = {
+    "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world,
+    "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+    "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+    "dtype": "f32", "data": "synthetic",
+    "config": {
+      "workload": "configs[1]: OT free dim=2, batch=65536, sample_and_log_prob (RQS fwd + log|detJ|), "
+                  "L=2 H=16 M=2 K=5, params N(0,%.2f^2) seed 42" % args.param_scale,
+      "batch": BATCH, "dim": DIM, "batch_per_gpu": b_local,
+      "slices_per_launch": S, "launches": len(events), "parallelism": f"sample-shard x{world}",
+    },
+    "roofline": {
+      "bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+      "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": None,
+      "kernel": "flow_kernel<16,5,to_base=false,fast>", "launch_ms": k_dur * 1e3,
+      "samples_per_launch": k_samples, "flop_per_sample": FLOP_PER_SAMPLE,
+      "note": "fp32 ALU bound: fp32 vector peak == fp32 MFMA peak (157.3 TFLOP/s) on gfx950; "
+              "HBM view: %.1f GB/s of %.0f (%.3f)" % (achieved_gbs, PEAK_HBM_GBS, achieved_gbs / PEAK_HBM_GBS),
+    },
+  }
+  pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+  if os.path.exists(pmc):
+    with open(pmc) as f:
+      rec = json.load(f)
+    if rec.get("samples_per_launch"):
+      line["roofline"]["traffic"] = rec["bytes_per_launch"] * k_samples / rec["samples_per_launch"]
+      line["roofline"]["traffic_source"] = rec.get("source", "profiles/hbm_traffic.json")
+
+  if not args.no_per_call and rank == 0 and world == 1:
+    n_calls = 200
+    for _ in range(20):
+      eng.sample_logprob(noise_flat[:b_local], t_slices[:1], out=y[:b_local], logp_out=lp[:b_local])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_calls):
+      eng.sample_logprob(noise_flat[:b_local], t_slices[i % S:i % S + 1], out=y[:b_local], logp_out=lp[:b_local])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    line["per_call"] = {"ms_per_step": dt / n_calls * 1e3, "value": n_calls * BATCH / dt,
+                        "note": "one launch per 65536-sample step, eager, same kernel"}
+
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    line["cpu_baseline"] = cpu_baseline(params.flat.cpu().double().numpy(), args.cpu_seconds)
+  elif rank == 0:
+    line["cpu_baseline"] = None
+
+  if rank == 0:
+    print(json.dumps(line), flush=True)
+  if dist is not None:
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

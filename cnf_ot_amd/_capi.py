@@ -1,0 +1,88 @@
+"""ctypes binding of libcnf_ot_amd.so -- the C ABI declared in
+include/cnf_ot_amd.h.  This is the stub a cnf_ot maintainer would add to call
+the MI355X engine from Python.
+
+There is NO CPU fallback: if the HIP library is missing or does not load,
+importing the product path fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcnf_ot_amd.so")
+
+CNF_OK = 0
+CNF_ERR_INVALID = -22
+CNF_ERR_UNSUPPORTED = -95
+CNF_ERR_NOMEM = -12
+CNF_ERR_HIP = -5
+
+
+class CnfConfig(ctypes.Structure):
+  _fields_ = [
+    ("dim", ctypes.c_int32), ("num_layers", ctypes.c_int32),
+    ("hidden_size", ctypes.c_int32), ("mlp_num_layers", ctypes.c_int32),
+    ("num_bins", ctypes.c_int32),
+    ("range_min", ctypes.c_float), ("range_max", ctypes.c_float),
+    ("min_bin_size", ctypes.c_float), ("min_knot_slope", ctypes.c_float),
+  ]
+
+
+# name -> (restype, argtypes); every symbol include/cnf_ot_amd.h declares
+_P = ctypes.c_void_p
+_I64 = ctypes.c_int64
+_U64 = ctypes.c_uint64
+_CFG = ctypes.POINTER(CnfConfig)
+SYMBOLS = {
+  "cnf_config_default": (None, [_CFG, ctypes.c_int32]),
+  "cnf_param_count": (_I64, [_CFG]),
+  "cnf_model_create": (ctypes.c_int, [_CFG, ctypes.POINTER(_P)]),
+  "cnf_model_destroy": (None, [_P]),
+  "cnf_model_set_params": (ctypes.c_int, [_P, _P, _P]),
+  "cnf_forward_logdet": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
+  "cnf_inverse_logdet": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
+  "cnf_log_prob": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _P]),
+  "cnf_sample_logprob": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
+  "cnf_fill_normal": (ctypes.c_int, [_U64, _U64, _I64, _P, _P]),
+  "cnf_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+  "cnf_build_arch": (ctypes.c_char_p, []),
+  "cnf_config_supported": (ctypes.c_int, [_CFG]),
+}
+# internal knobs (not part of the public header)
+_INTERNAL = {
+  "cnf_model_set_fast_math": (ctypes.c_int, [_P, ctypes.c_int]),
+}
+
+_lib = None
+
+
+class CnfError(RuntimeError):
+  def __init__(self, code, where):
+    self.code = code
+    msg = lib().cnf_strerror(code).decode() if _lib is not None else str(code)
+    super().__init__(f"{where}: {msg} ({code})")
+
+
+def lib():
+  """Load the HIP library (once).  Raises if it is absent: no fallback."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise ImportError(
+      f"{LIB_PATH} is missing: the cnf_ot_amd product path is hand-written HIP "
+      "for gfx950 and has no CPU fallback. Build it with "
+      "`python -m cnf_ot_amd.build` (needs hipcc).")
+  handle = ctypes.CDLL(LIB_PATH)
+  for table in (SYMBOLS, _INTERNAL):
+    for name, (res, args) in table.items():
+      fn = getattr(handle, name)   # AttributeError if the export is missing
+      fn.restype = res
+      fn.argtypes = args
+  _lib = handle
+  return _lib
+
+
+def check(code, where):
+  if code != CNF_OK:
+    raise CnfError(code, where)

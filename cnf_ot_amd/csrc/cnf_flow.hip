@@ -1,0 +1,464 @@
+// cnf_flow.hip -- gfx950 kernels and C ABI of the conditional RQS flow engine.
+// Declarations and the reference interfaces they replace: include/cnf_ot_amd.h.
+//
+// Kernel design (DESIGN.md has the numbers):
+//  * one sample per lane, a 256-sample tile per workgroup, grid-stride over
+//    tiles; the tile's [256, D] rows are one contiguous HBM range, so loads and
+//    stores are fully coalesced and transposed through LDS into per-thread
+//    columns u[d][tid] (conflict-free per-lane access);
+//  * all L layers, all D dimensions, conditioner MLP + spline + log|det J|
+//    accumulate are fused: HBM sees only the input row, the output row and one
+//    float of log-det / log-prob per sample;
+//  * conditioner weights are wave-uniform: they reach the per-lane FMAs as
+//    scalar (SGPR) operands through the scalar cache, not through LDS/VGPRs;
+//  * the shared `first` spline is pre-normalised (float64, once per parameter
+//    set) into a 12-float-per-bin table that is staged in LDS and gathered by
+//    per-lane bin index.
+#include "cnf_device.h"
+#include "../../include/cnf_ot_amd.h"
+
+#include <math.h>
+#include <new>
+#include <stdlib.h>
+#include <string.h>
+
+namespace cnf {
+
+constexpr int TILE = 256;
+constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
+
+enum CMode { C_SINGLE = 0, C_PER_SAMPLE = 1, C_TILE_UNIFORM = 2, C_GENERIC = 3 };
+enum AuxMode { AUX_LOGDET = 0, AUX_LOGPROB = 1 };
+
+struct FlowArgs {
+  const float* prep;     // prepared model buffer
+  const float* in;       // [B, D]
+  const float* c;        // conditions
+  float* out;            // [B, D] or null
+  float* aux;            // [B] logdet / logprob, or null
+  int64_t B;
+  int64_t c_block;
+  int64_t per_layer;     // floats of conditioner weights per flow layer
+  int32_t D, L, M;
+  int32_t c_mode, aux_mode;
+  SplineConsts sc;
+};
+
+// ---------------------------------------------------------------------------
+// prepare_kernel: params (flat, caller-owned) -> prepared model buffer.
+// Thread 0 normalises the `first` spline in float64; all threads snapshot the
+// conditioner weights.
+// ---------------------------------------------------------------------------
+__global__ void prepare_kernel(const float* __restrict__ params, float* __restrict__ prep,
+                               int K, int64_t n_params, double lo, double hi, double min_bin,
+                               double min_slope) {
+  const int P = 3 * K + 1;
+  const int hdr = hdr_floats(K);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_params - P;
+       i += (int64_t)gridDim.x * blockDim.x)
+    prep[hdr + i] = params[P + i];
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+
+  constexpr int MAXK = 64;
+  double xk[MAXK + 1], yk[MAXK + 1], dl[MAXK + 1];
+  const double total = (hi - lo) - K * min_bin;
+  for (int part = 0; part < 2; ++part) {
+    const float* u = params + part * K;
+    double* pos = part == 0 ? xk : yk;
+    double mx = u[0];
+    for (int k = 1; k < K; ++k) mx = fmax(mx, (double)u[k]);
+    double sum = 0;
+    for (int k = 0; k < K; ++k) sum += exp((double)u[k] - mx);
+    double run = 0;
+    pos[0] = lo;
+    for (int k = 0; k < K - 1; ++k) {
+      run += exp((double)u[k] - mx) / sum * total + min_bin;
+      pos[k + 1] = lo + run;
+    }
+    pos[K] = hi;
+  }
+  const double offset = log(exp(1.0 - min_slope) - 1.0);
+  for (int k = 0; k <= K; ++k) {
+    const double v = (double)params[2 * K + k] + offset;
+    dl[k] = fmax(v, 0.0) + log1p(exp(-fabs(v))) + min_slope;
+  }
+  for (int k = 0; k < K; ++k) {
+    float* r = prep + k * ROW;
+    const double bw = xk[k + 1] - xk[k], bh = yk[k + 1] - yk[k], s = bh / bw;
+    r[R_X0] = (float)xk[k];  r[R_Y0] = (float)yk[k];
+    r[R_BW] = (float)bw;     r[R_BH] = (float)bh;
+    r[R_IBW] = (float)(1.0 / bw); r[R_IBH] = (float)(1.0 / bh);
+    r[R_S] = (float)s;       r[R_ST] = (float)(dl[k + 1] + dl[k] - 2.0 * s);
+    r[R_D0] = (float)dl[k];  r[R_D1] = (float)dl[k + 1];
+    r[R_L2S] = (float)(2.0 * log(s)); r[R_PAD] = 0.0f;
+  }
+  for (int k = 0; k <= K; ++k) {
+    prep[knot_x_off(K) + k] = (float)xk[k];
+    prep[knot_y_off(K) + k] = (float)yk[k];
+  }
+  float* tl = prep + tail_off(K);
+  tl[T_DLO] = (float)dl[0];             tl[T_DHI] = (float)dl[K];
+  tl[T_LOG_DLO] = (float)log(dl[0]);    tl[T_LOG_DHI] = (float)log(dl[K]);
+  tl[T_INV_DLO] = (float)(1.0 / dl[0]); tl[T_INV_DHI] = (float)(1.0 / dl[K]);
+  for (int i = tail_off(K) + 6; i < hdr; ++i) prep[i] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------
+// LDS tile: [hdr table][U: D x STRIDE][O: D x STRIDE]
+// ---------------------------------------------------------------------------
+constexpr int STRIDE = TILE;   // per-thread columns: lane-consecutive, conflict-free
+
+__device__ __forceinline__ void tile_load(const float* __restrict__ g, float* U, int D,
+                                          int64_t tile_start, int64_t B) {
+  const int64_t base = tile_start * D;
+  const int64_t n_el = (B - tile_start < TILE ? B - tile_start : TILE) * (int64_t)D;
+  for (int e = threadIdx.x; e < TILE * D; e += TILE) {
+    const int s = e / D, d = e - s * D;
+    U[d * STRIDE + s] = e < n_el ? g[base + e] : 0.0f;
+  }
+}
+
+__device__ __forceinline__ void tile_store(float* __restrict__ g, const float* U, int D,
+                                           int64_t tile_start, int64_t B) {
+  const int64_t base = tile_start * D;
+  const int64_t n_el = (B - tile_start < TILE ? B - tile_start : TILE) * (int64_t)D;
+  for (int e = threadIdx.x; e < TILE * D; e += TILE) {
+    const int s = e / D, d = e - s * D;
+    if (e < n_el) g[base + e] = U[d * STRIDE + s];
+  }
+}
+
+__device__ __forceinline__ float load_cond(const FlowArgs& a, int64_t tile_start, int64_t i) {
+  switch (a.c_mode) {
+    case C_SINGLE: return a.c[0];
+    case C_PER_SAMPLE: return i < a.B ? a.c[i] : 0.0f;
+    case C_TILE_UNIFORM: return a.c[tile_start / a.c_block];
+    default: return i < a.B ? a.c[i / a.c_block] : 0.0f;
+  }
+}
+
+// One pass of the whole flow over the thread's own sample, in place in LDS.
+// TO_BASE=false: base -> data (chain.inverse, spline inverse, conditions on the
+// layer input: conditional.py:169-177, autoregressive.py:109-136).
+// TO_BASE=true : data -> base (chain.forward, spline forward, conditions on
+// already-produced outputs: conditional.py:159-167, autoregressive.py:76-107).
+// Returns the accumulated log|det J|; the result is left in `U` (swapped).
+template <int H, int K, bool TO_BASE, bool FAST>
+__device__ __forceinline__ float flow_pass(const FlowArgs& a, const float* tab, float*& U,
+                                           float*& O, float c) {
+  constexpr int P = 3 * K + 1;
+  constexpr bool INV = !TO_BASE;
+  uniform_ptr weights = as_uniform(a.prep + hdr_floats(K));
+  const int D = a.D;
+  float acc = 0.0f;
+  for (int step = 0; step < a.L; ++step) {
+    const int l = TO_BASE ? a.L - 1 - step : step;
+    const bool odd = l & 1;                       // flows.py:141-143 perms
+    const int first_idx = odd ? D - 1 : 0, idx_step = odd ? -1 : 1;
+    float* cu = U + threadIdx.x;
+    float* co = O + threadIdx.x;
+    float o, ld;
+    table_spline<K, INV, FAST>(tab, cu[first_idx * STRIDE], a.sc, o, ld);
+    co[first_idx * STRIDE] = o;
+    acc += ld;
+    uniform_ptr w = weights + l * a.per_layer;
+    for (int d = 1; d < D; ++d) {
+      const int i = first_idx + d * idx_step;
+      float th[P];
+      conditioner<H, P>(w, d, a.M, c, TO_BASE ? co : cu, first_idx, idx_step, STRIDE, th);
+      cond_spline<K, INV, FAST>(th, cu[i * STRIDE], a.sc, o, ld);
+      co[i * STRIDE] = o;
+      acc += ld;
+      w += cond_floats(d, H, a.M, P);
+    }
+    float* t = U; U = O; O = t;
+  }
+  return acc;
+}
+
+template <int H, int K, bool TO_BASE, bool FAST>
+__global__ __launch_bounds__(TILE) void flow_kernel(const FlowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int HDR = hdr_floats(K);
+  float* tab = lds;
+  float* U = lds + HDR;
+  float* O = U + a.D * STRIDE;
+  for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = a.prep[i];
+
+  const int64_t n_tiles = (a.B + TILE - 1) / TILE;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t tile_start = tile * TILE;
+    const int64_t i = tile_start + threadIdx.x;
+    __syncthreads();                       // previous tile's stores are done with U/O
+    tile_load(a.in, U, a.D, tile_start, a.B);
+    const float c = load_cond(a, tile_start, i);
+    __syncthreads();
+
+    float base = 0.0f;
+    if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) {
+      for (int d = 0; d < a.D; ++d) { const float x = U[d * STRIDE + threadIdx.x]; base = fmaf(-0.5f * x, x, base); }
+      base -= a.D * HALF_LOG_2PI;
+    }
+    const float acc = flow_pass<H, K, TO_BASE, FAST>(a, tab, U, O, c);
+    if (a.aux && i < a.B) {
+      float r = acc;
+      if (a.aux_mode == AUX_LOGPROB) {
+        if (TO_BASE) {   // log_prob = base(x) + ildj (conditional.py:316-321)
+          float b = 0.0f;
+          for (int d = 0; d < a.D; ++d) { const float x = U[d * STRIDE + threadIdx.x]; b = fmaf(-0.5f * x, x, b); }
+          r = b - a.D * HALF_LOG_2PI + acc;
+        } else {         // lp_y = lp_x - fldj (conditional.py:399-401)
+          r = base - acc;
+        }
+      }
+      a.aux[i] = r;
+    }
+    if (a.out) {
+      __syncthreads();
+      tile_store(a.out, U, a.D, tile_start, a.B);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Base noise: Philox4x32-10 + Box-Muller; one counter block (4 normals) per
+// thread.  Element e of the stream uses block e>>2, word pair (e&3)>>1.
+// ---------------------------------------------------------------------------
+__global__ void fill_normal_kernel(uint64_t seed, uint64_t first_element, int64_t n,
+                                   float* __restrict__ out) {
+  const uint64_t first_blk = first_element >> 2;
+  const uint64_t last_blk = (first_element + (uint64_t)n - 1) >> 2;
+  for (uint64_t blk = first_blk + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; blk <= last_blk;
+       blk += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t u[4];
+    philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), u);
+    float z[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const float u1 = (float)((u[2 * p] >> 8) + 1u) * (1.0f / 16777216.0f);
+      const float u2 = (float)(u[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
+      const float rad = sqrtf(-2.0f * logf(u1));
+      float sn, cs;
+      sincospif(2.0f * u2, &sn, &cs);
+      z[2 * p] = rad * cs;
+      z[2 * p + 1] = rad * sn;
+    }
+    const uint64_t e0 = blk << 2;
+    if (e0 >= first_element && e0 + 3 < first_element + (uint64_t)n && (((e0 - first_element) & 3) == 0) &&
+        ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+      *reinterpret_cast<float4*>(out + (e0 - first_element)) = make_float4(z[0], z[1], z[2], z[3]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint64_t e = e0 + r;
+        if (e >= first_element && e < first_element + (uint64_t)n) out[e - first_element] = z[r];
+      }
+    }
+  }
+}
+
+}  // namespace cnf
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+using namespace cnf;
+
+struct CnfModel {
+  CnfConfig cfg;
+  SplineConsts sc;
+  float* prep;            // device
+  int64_t n_params;
+  int64_t per_layer;
+  int device;
+  int num_cus;
+  int fast_math;          // 1: hardware transcendentals (default), 0: ocml
+  int params_set;
+};
+
+#ifdef CNF_MINIMAL_CONFIGS   /* faster builds while iterating on the kernels */
+#define CNF_KERNEL_CONFIGS(X) X(16, 5)
+#else
+#define CNF_KERNEL_CONFIGS(X) \
+  X(8, 4) X(8, 5) X(8, 8)     \
+  X(16, 4) X(16, 5) X(16, 8) X(16, 10) \
+  X(32, 5) X(32, 8) X(32, 10) \
+  X(64, 5) X(64, 8)
+#endif
+
+static int config_valid(const CnfConfig* c) {
+  if (!c) return 0;
+  if (c->dim < 1 || c->dim > 64) return 0;
+  if (c->num_layers < 1 || c->num_layers > 64) return 0;
+  if (c->hidden_size < 1 || c->mlp_num_layers < 1 || c->mlp_num_layers > 16) return 0;
+  if (c->num_bins < 1 || c->num_bins > 64) return 0;
+  if (!(c->range_min < c->range_max)) return 0;
+  if (!(c->min_bin_size > 0.f) || !(c->min_knot_slope > 0.f) || !(c->min_knot_slope < 1.f)) return 0;
+  if (c->num_bins * c->min_bin_size > c->range_max - c->range_min) return 0;   // distrax raises
+  return 1;
+}
+
+extern "C" int cnf_config_supported(const CnfConfig* c) {
+  if (!config_valid(c)) return 0;
+#define X(HH, KK) if (c->hidden_size == HH && c->num_bins == KK) return 1;
+  CNF_KERNEL_CONFIGS(X)
+#undef X
+  return 0;
+}
+
+extern "C" void cnf_config_default(CnfConfig* c, int32_t dim) {
+  if (!c) return;
+  c->dim = dim; c->num_layers = 2; c->hidden_size = 16; c->mlp_num_layers = 2; c->num_bins = 5;
+  c->range_min = -10.f; c->range_max = 10.f; c->min_bin_size = 1e-4f; c->min_knot_slope = 1e-4f;
+}
+
+extern "C" int64_t cnf_param_count(const CnfConfig* c) {
+  if (!config_valid(c)) return CNF_ERR_INVALID;
+  const int P = 3 * c->num_bins + 1;
+  int64_t n = P;
+  for (int d = 1; d < c->dim; ++d)
+    n += (int64_t)c->num_layers * cond_floats(d, c->hidden_size, c->mlp_num_layers, P);
+  return n;
+}
+
+extern "C" const char* cnf_strerror(int code) {
+  switch (code) {
+    case CNF_OK: return "ok";
+    case CNF_ERR_INVALID: return "invalid argument";
+    case CNF_ERR_UNSUPPORTED: return "no kernel compiled for this (hidden_size, num_bins)";
+    case CNF_ERR_NOMEM: return "out of memory";
+    case CNF_ERR_HIP: return "HIP runtime error";
+    default: return "unknown error";
+  }
+}
+
+extern "C" const char* cnf_build_arch(void) { return "gfx950"; }
+
+extern "C" int cnf_model_create(const CnfConfig* cfg, CnfModel** out) {
+  if (!out) return CNF_ERR_INVALID;
+  *out = nullptr;
+  if (!config_valid(cfg)) return CNF_ERR_INVALID;
+  if (!cnf_config_supported(cfg)) return CNF_ERR_UNSUPPORTED;
+  CnfModel* m = new (std::nothrow) CnfModel;
+  if (!m) return CNF_ERR_NOMEM;
+  memset(m, 0, sizeof(*m));
+  m->cfg = *cfg;
+  const int K = cfg->num_bins, P = 3 * K + 1;
+  m->n_params = cnf_param_count(cfg);
+  m->per_layer = 0;
+  for (int d = 1; d < cfg->dim; ++d) m->per_layer += cond_floats(d, cfg->hidden_size, cfg->mlp_num_layers, P);
+  m->sc.lo = cfg->range_min; m->sc.hi = cfg->range_max;
+  m->sc.min_bin = cfg->min_bin_size; m->sc.min_slope = cfg->min_knot_slope;
+  m->sc.span_eff = (float)(((double)cfg->range_max - (double)cfg->range_min) - (double)K * (double)cfg->min_bin_size);
+  m->sc.sp_offset = (float)log(exp(1.0 - (double)cfg->min_knot_slope) - 1.0);
+  m->fast_math = 1;
+  if (hipGetDevice(&m->device) != hipSuccess) { delete m; return CNF_ERR_HIP; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, m->device) != hipSuccess) { delete m; return CNF_ERR_HIP; }
+  m->num_cus = prop.multiProcessorCount;
+  const size_t bytes = (size_t)(hdr_floats(K) + (m->n_params - P)) * sizeof(float) + 64;
+  if (hipMalloc((void**)&m->prep, bytes) != hipSuccess) { delete m; return CNF_ERR_NOMEM; }
+  *out = m;
+  return CNF_OK;
+}
+
+extern "C" void cnf_model_destroy(CnfModel* m) {
+  if (!m) return;
+  if (m->prep) (void)hipFree(m->prep);
+  delete m;
+}
+
+/* Internal knob used by the tests and the bench: 1 = hardware transcendentals
+ * (default), 0 = ocml expf/logf/sqrtf + IEEE division. */
+extern "C" int cnf_model_set_fast_math(CnfModel* m, int on) {
+  if (!m) return CNF_ERR_INVALID;
+  m->fast_math = on ? 1 : 0;
+  return CNF_OK;
+}
+
+extern "C" int cnf_model_set_params(CnfModel* m, const float* params, void* stream) {
+  if (!m || !params) return CNF_ERR_INVALID;
+  const int K = m->cfg.num_bins;
+  const int64_t n_w = m->n_params - (3 * K + 1);
+  int blocks = (int)((n_w + 255) / 256);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(prepare_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, m->prep, K,
+                     m->n_params, (double)m->cfg.range_min, (double)m->cfg.range_max,
+                     (double)m->cfg.min_bin_size, (double)m->cfg.min_knot_slope);
+  if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
+  m->params_set = 1;
+  return CNF_OK;
+}
+
+template <bool TO_BASE>
+static int launch_flow(CnfModel* m, const FlowArgs& a, hipStream_t stream) {
+  const int64_t n_tiles = (a.B + TILE - 1) / TILE;
+  int64_t grid = n_tiles;
+  const int64_t cap = (int64_t)m->num_cus * 8;
+  if (grid > cap) grid = cap;
+  const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.D * STRIDE) * sizeof(float);
+#define X(HH, KK)                                                                             \
+  if (m->cfg.hidden_size == HH && m->cfg.num_bins == KK) {                                    \
+    if (m->fast_math)                                                                         \
+      hipLaunchKernelGGL((flow_kernel<HH, KK, TO_BASE, true>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);  \
+    else                                                                                      \
+      hipLaunchKernelGGL((flow_kernel<HH, KK, TO_BASE, false>), dim3((unsigned)grid), dim3(TILE), lds, stream, a); \
+    return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;                            \
+  }
+  CNF_KERNEL_CONFIGS(X)
+#undef X
+  return CNF_ERR_UNSUPPORTED;
+}
+
+static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, int64_t c_block,
+                    float* out, float* aux, int aux_mode, int64_t B, void* stream) {
+  if (!m || !in || !c || B < 0 || c_block < 1) return CNF_ERR_INVALID;
+  if (!out && !aux) return CNF_ERR_INVALID;
+  if (!m->params_set) return CNF_ERR_INVALID;
+  if (B == 0) return CNF_OK;
+  FlowArgs a;
+  a.prep = m->prep; a.in = in; a.c = c; a.out = out; a.aux = aux;
+  a.B = B; a.c_block = c_block; a.per_layer = m->per_layer;
+  a.D = m->cfg.dim; a.L = m->cfg.num_layers; a.M = m->cfg.mlp_num_layers;
+  a.aux_mode = aux_mode; a.sc = m->sc;
+  if (c_block >= B) a.c_mode = C_SINGLE;
+  else if (c_block == 1) a.c_mode = C_PER_SAMPLE;
+  else if (c_block % TILE == 0) a.c_mode = C_TILE_UNIFORM;
+  else a.c_mode = C_GENERIC;
+  return to_base ? launch_flow<true>(m, a, (hipStream_t)stream) : launch_flow<false>(m, a, (hipStream_t)stream);
+}
+
+extern "C" int cnf_forward_logdet(CnfModel* m, const float* x, const float* c, int64_t c_block,
+                                  float* y, float* logdet, int64_t B, void* stream) {
+  return run_flow(m, false, x, c, c_block, y, logdet, AUX_LOGDET, B, stream);
+}
+
+extern "C" int cnf_inverse_logdet(CnfModel* m, const float* y, const float* c, int64_t c_block,
+                                  float* x, float* logdet, int64_t B, void* stream) {
+  return run_flow(m, true, y, c, c_block, x, logdet, AUX_LOGDET, B, stream);
+}
+
+extern "C" int cnf_log_prob(CnfModel* m, const float* value, const float* c, int64_t c_block,
+                            float* logp, int64_t B, void* stream) {
+  if (!logp) return CNF_ERR_INVALID;
+  return run_flow(m, true, value, c, c_block, nullptr, logp, AUX_LOGPROB, B, stream);
+}
+
+extern "C" int cnf_sample_logprob(CnfModel* m, const float* noise, const float* c, int64_t c_block,
+                                  float* y, float* logp, int64_t B, void* stream) {
+  if (!y) return CNF_ERR_INVALID;
+  return run_flow(m, false, noise, c, c_block, y, logp, AUX_LOGPROB, B, stream);
+}
+
+extern "C" int cnf_fill_normal(uint64_t seed, uint64_t first_element, int64_t n, float* out,
+                               void* stream) {
+  if (n < 0 || (n > 0 && !out)) return CNF_ERR_INVALID;
+  if (n == 0) return CNF_OK;
+  const uint64_t n_blk = ((first_element + (uint64_t)n - 1) >> 2) - (first_element >> 2) + 1;
+  uint64_t grid = (n_blk + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, seed,
+                     first_element, n, out);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}

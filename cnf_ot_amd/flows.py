@@ -1,0 +1,321 @@
+"""Host-side mirror of cnf_ot's flow-model call surface on PyTorch-ROCm tensors.
+
+``RQSFlow(...)`` here returns what the reference gets from
+``hk.without_apply_rng(hk.multi_transform(RQSFlow(...)))``
+(cnf_ot/models/flows.py:178-226, cnf_ot/mfc/solvers.py:41-54): an object with
+``init(rng, x, c) -> params`` and ``apply.<fn>(params, ...)`` for the eight
+functions of the reference's ``Flow`` namedtuple.  All arithmetic runs in the
+hand-written HIP kernels behind the C ABI (include/cnf_ot_amd.h); torch is
+only device memory and streams.
+"""
+import math
+from collections import namedtuple
+from typing import Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _capi
+from .params import FlowConfig, Params, flatten
+
+Flow = namedtuple("Flow", [
+  "log_prob", "sample", "sample_and_log_prob", "forward", "inverse",
+  "forward_jac", "inverse_jac", "gauge_potential",
+])
+
+_MASK64 = (1 << 64) - 1
+
+
+def _c_config(cfg: FlowConfig) -> _capi.CnfConfig:
+  return _capi.CnfConfig(cfg.dim, cfg.num_layers, cfg.hidden_size, cfg.mlp_num_layers,
+                         cfg.num_bins, cfg.range_min, cfg.range_max, cfg.min_bin_size,
+                         cfg.min_knot_slope)
+
+
+def _stream_ptr(device) -> int:
+  return torch.cuda.current_stream(device).cuda_stream
+
+
+def seed_to_u64(seed) -> Tuple[int, int]:
+  """int | (seed, first_sample) | 2-word PRNGKey-like array -> (u64 seed, first_sample)."""
+  offset = 0
+  if isinstance(seed, tuple) and len(seed) == 2 and not torch.is_tensor(seed[0]):
+    seed, offset = seed
+  if torch.is_tensor(seed) or isinstance(seed, np.ndarray):
+    words = [int(v) for v in np.asarray(seed.cpu() if torch.is_tensor(seed) else seed).reshape(-1)]
+    if len(words) == 1:
+      seed = words[0]
+    elif len(words) == 2:   # jax.random.PRNGKey layout: two uint32 words
+      seed = ((words[0] & 0xFFFFFFFF) << 32) | (words[1] & 0xFFFFFFFF)
+    else:
+      raise ValueError("seed array must have 1 or 2 words")
+  return int(seed) & _MASK64, int(offset)
+
+
+class FlowEngine:
+  """One CnfModel handle (C ABI) on one GPU.  Explicit, allocation-light API
+  used by the loss code, the evaluators and bench.py."""
+
+  def __init__(self, cfg: FlowConfig, device: Union[str, torch.device, int] = "cuda"):
+    self.lib = _capi.lib()            # raises if the HIP library is missing
+    self.cfg = cfg
+    self.device = torch.device(device)
+    if self.device.type != "cuda":
+      raise ValueError("cnf_ot_amd runs on MI355X only: pass a cuda (ROCm) device")
+    if self.device.index is None:
+      self.device = torch.device("cuda", torch.cuda.current_device())
+    ccfg = _c_config(cfg)
+    handle = _capi.ctypes.c_void_p()
+    with torch.cuda.device(self.device):
+      _capi.check(self.lib.cnf_model_create(_capi.ctypes.byref(ccfg), _capi.ctypes.byref(handle)),
+                  "cnf_model_create")
+    self._h = handle
+    self._flat = None                 # keeps the caller's flat tensor alive
+
+  def __del__(self):
+    h = getattr(self, "_h", None)
+    if h:
+      try:
+        self.lib.cnf_model_destroy(h)
+      except Exception:
+        pass
+      self._h = None
+
+  # -- parameters ------------------------------------------------------------
+  def load(self, params) -> "FlowEngine":
+    """cnf_model_set_params: prepare the `first` table + snapshot the weights."""
+    flat = flatten(self.cfg, params, self.device)
+    with torch.cuda.device(self.device):
+      _capi.check(self.lib.cnf_model_set_params(self._h, flat.data_ptr(), _stream_ptr(self.device)),
+                  "cnf_model_set_params")
+    self._flat = flat
+    return self
+
+  def set_fast_math(self, on: bool) -> None:
+    _capi.check(self.lib.cnf_model_set_fast_math(self._h, 1 if on else 0), "cnf_model_set_fast_math")
+
+  # -- helpers ---------------------------------------------------------------
+  def _points(self, t, what) -> torch.Tensor:
+    if not torch.is_tensor(t):
+      t = torch.as_tensor(np.asarray(t))
+    if t.dim() != 2 or t.shape[1] != self.cfg.dim:
+      # the reference checks the event shape at trace time (autoregressive.py:80,113)
+      raise ValueError(f"{what}: expected shape [B, {self.cfg.dim}], got {tuple(t.shape)}")
+    return t.to(device=self.device, dtype=torch.float32).contiguous()
+
+  def cond(self, cond, B: int) -> Tuple[torch.Tensor, int]:
+    """cond -> (flat float32 device tensor, c_block).  [B,1]/[B]: per sample;
+    scalar/[1]: broadcast; [S]/[S,1] with B % S == 0: S equal slices."""
+    if not torch.is_tensor(cond):
+      cond = torch.as_tensor(np.asarray(cond, dtype=np.float32))
+    c = cond.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+    n = c.numel()
+    if n == 0:
+      raise ValueError("cond is empty")
+    if n == 1:
+      return c, max(B, 1)
+    if n == B:
+      return c, 1
+    if B % n == 0:
+      return c, B // n
+    raise ValueError(f"cond with {n} values does not tile a batch of {B}")
+
+  def _check_out(self, t, shape, what):
+    if (t.dtype != torch.float32 or t.device != self.device or not t.is_contiguous()
+        or tuple(t.shape) != tuple(shape)):
+      raise ValueError(f"{what}: need a contiguous float32 {tuple(shape)} tensor on {self.device}")
+    return t
+
+  def _run(self, fn, name, pts, cond, want_pts, want_aux, out=None, aux=None):
+    B = pts.shape[0]
+    c, c_block = self.cond(cond, B)
+    if out is not None:
+      self._check_out(out, pts.shape, name + " out")
+    elif want_pts:
+      out = torch.empty_like(pts)
+    if aux is not None:
+      self._check_out(aux, (B,), name + " aux")
+    elif want_aux:
+      aux = torch.empty(B, dtype=torch.float32, device=self.device)
+    if B > 0:
+      with torch.cuda.device(self.device):
+        _capi.check(fn(self._h, pts.data_ptr(), c.data_ptr(), c_block,
+                       out.data_ptr() if out is not None else None,
+                       aux.data_ptr() if aux is not None else None, B,
+                       _stream_ptr(self.device)), name)
+    return out, aux
+
+  # -- the C ABI, on tensors -------------------------------------------------
+  def forward_logdet(self, x, cond, want_logdet=True):
+    """base -> data: (y [B,D], log|det J| [B])."""
+    x = self._points(x, "forward")
+    return self._run(self.lib.cnf_forward_logdet, "cnf_forward_logdet", x, cond, True, want_logdet)
+
+  def inverse_logdet(self, y, cond, want_logdet=True):
+    """data -> base: (x [B,D], log|det J^-1| [B])."""
+    y = self._points(y, "inverse")
+    return self._run(self.lib.cnf_inverse_logdet, "cnf_inverse_logdet", y, cond, True, want_logdet)
+
+  def log_prob(self, value, cond) -> torch.Tensor:
+    value = self._points(value, "log_prob")
+    B = value.shape[0]
+    c, c_block = self.cond(cond, B)
+    lp = torch.empty(B, dtype=torch.float32, device=self.device)
+    if B > 0:
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_log_prob(self._h, value.data_ptr(), c.data_ptr(), c_block,
+                                          lp.data_ptr(), B, _stream_ptr(self.device)), "cnf_log_prob")
+    return lp
+
+  def sample_logprob(self, noise, cond, want_logp=True, out=None, logp_out=None):
+    """(samples [B,D], log_prob [B]) from base noise [B,D].  `out` / `logp_out`
+    are optional preallocated result tensors (no allocation on the call)."""
+    noise = self._points(noise, "sample")
+    return self._run(self.lib.cnf_sample_logprob, "cnf_sample_logprob", noise, cond, True, want_logp,
+                     out=out, aux=logp_out)
+
+  def normal(self, seed, n_samples: int, first_sample: int = 0) -> torch.Tensor:
+    """Base noise [n_samples, D]: Philox stream element (first_sample+i)*D+d."""
+    seed, off = seed_to_u64(seed)
+    D = self.cfg.dim
+    out = torch.empty(n_samples, D, dtype=torch.float32, device=self.device)
+    if n_samples > 0:
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_fill_normal(seed, (off + first_sample) * D, n_samples * D,
+                                             out.data_ptr(), _stream_ptr(self.device)), "cnf_fill_normal")
+    return out
+
+
+def _num_samples(sample_shape) -> Tuple[int, Tuple[int, ...]]:
+  if isinstance(sample_shape, (int, np.integer)):
+    sample_shape = (int(sample_shape),)
+  sample_shape = tuple(int(s) for s in sample_shape)
+  return int(np.prod(sample_shape)) if sample_shape else 1, sample_shape
+
+
+class _Apply:
+  """model.apply: pure functions of (params, ...), like hk's Transformed.apply."""
+
+  def __init__(self, model: "FlowModel"):
+    self._m = model
+
+  def _engine(self, params, like=None) -> FlowEngine:
+    device = None
+    if isinstance(params, Params):
+      device = params.flat.device
+    if (device is None or device.type != "cuda") and torch.is_tensor(like) and like.is_cuda:
+      device = like.device
+    if device is None or device.type != "cuda":
+      device = torch.device("cuda", torch.cuda.current_device())
+    return self._m.engine(device).load(params)
+
+  # conditional.py:316-321
+  def log_prob(self, params, value, cond=None):
+    if cond is None:
+      raise ValueError("log_prob needs `cond` (the flow is conditional, cond_shape=(1,))")
+    return self._engine(params, value).log_prob(value, cond)
+
+  def _draw(self, eng, cond, seed, sample_shape, noise):
+    n, shape = _num_samples(sample_shape)
+    if noise is None:
+      if seed is None:
+        raise ValueError("sample needs `seed` (or explicit base `noise`)")
+      noise = eng.normal(seed, n)
+    elif tuple(noise.shape) != (n, eng.cfg.dim):
+      raise ValueError(f"noise must have shape {(n, eng.cfg.dim)}, got {tuple(noise.shape)}")
+    return noise, shape
+
+  # conditional.py:323-351
+  def sample(self, params, *, cond, seed=None, sample_shape=(), noise=None):
+    eng = self._engine(params, cond if torch.is_tensor(cond) else None)
+    noise, shape = self._draw(eng, cond, seed, sample_shape, noise)
+    y, _ = eng.sample_logprob(noise, cond, want_logp=False)
+    return y.reshape(shape + (eng.cfg.dim,))
+
+  # conditional.py:353-374
+  def sample_and_log_prob(self, params, *, cond, seed=None, sample_shape=(), noise=None):
+    eng = self._engine(params, cond if torch.is_tensor(cond) else None)
+    noise, shape = self._draw(eng, cond, seed, sample_shape, noise)
+    y, lp = eng.sample_logprob(noise, cond, want_logp=True)
+    return y.reshape(shape + (eng.cfg.dim,)), lp.reshape(shape)
+
+  # flows.py:221-223: flow.bijector.forward / inverse
+  def forward(self, params, x, c):
+    return self._engine(params, x).forward_logdet(x, c, want_logdet=False)[0]
+
+  def inverse(self, params, y, c):
+    return self._engine(params, y).inverse_logdet(y, c, want_logdet=False)[0]
+
+  def _no_autodiff(self, name):
+    raise NotImplementedError(
+      f"{name} is a jax.jacfwd helper with no live call site in the reference "
+      "(flows.py:203-211; only a commented use in tests/test_fit_prob.py:140-142); "
+      "it is outside the hot-path scope of this build")
+
+  def forward_jac(self, params, x, c):
+    self._no_autodiff("forward_jac")
+
+  def inverse_jac(self, params, y, c):
+    self._no_autodiff("inverse_jac")
+
+  def gauge_potential(self, params, x, c):
+    self._no_autodiff("gauge_potential")
+
+
+class FlowModel:
+  """What the reference's driver holds after
+  ``hk.without_apply_rng(hk.multi_transform(RQSFlow(...)))`` (solvers.py:41-48)."""
+
+  def __init__(self, cfg: FlowConfig):
+    self.cfg = cfg
+    self._engines = {}
+    a = _Apply(self)
+    self.apply = Flow(a.log_prob, a.sample, a.sample_and_log_prob, a.forward, a.inverse,
+                      a.forward_jac, a.inverse_jac, a.gauge_potential)
+
+  def engine(self, device) -> FlowEngine:
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+      device = torch.device("cuda", torch.cuda.current_device())
+    eng = self._engines.get(device)
+    if eng is None:
+      eng = self._engines[device] = FlowEngine(self.cfg, device)
+    return eng
+
+  def init(self, rng=0, x=None, c=None, device=None) -> Params:
+    """model.init(rng, zeros((1,dim)), zeros((1,))) (solvers.py:54): identity
+    flow -- `first` and every linear_out zero (flows.py:48,71-76), hidden
+    layers at haiku's default init."""
+    if x is not None and (x.shape[-1] != self.cfg.dim):
+      raise ValueError(f"init: event dimension {x.shape[-1]} != {self.cfg.dim}")
+    seed, _ = seed_to_u64(rng)
+    if device is None:
+      device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu"
+    return Params.init(self.cfg, seed=seed % (2 ** 63), device=device)
+
+
+def RQSFlow(
+  event_shape: Sequence[int],
+  num_layers: int,
+  hidden_sizes: Sequence[int],
+  num_bins: int,
+  periodized: bool = False,
+  cond_shape=(1,),
+  base_range=(0, 2 * math.pi),
+) -> FlowModel:
+  """Same signature as cnf_ot/models/flows.py:178-186."""
+  if periodized:
+    raise NotImplementedError(
+      "periodized=True (circular boundary slopes on [0, 2pi]) is not on the mfc hot "
+      "path: every reference call site passes periodized=False (solvers.py:46)")
+  if len(tuple(event_shape)) != 1:
+    raise ValueError("event_shape must be (dim,)")
+  if tuple(cond_shape) != (1,):
+    raise NotImplementedError("only cond_shape=(1,) (time-conditioned flow) is supported")
+  hidden_sizes = list(hidden_sizes)
+  if not hidden_sizes or any(h != hidden_sizes[0] for h in hidden_sizes):
+    raise NotImplementedError("hidden_sizes must be [hidden_size] * mlp_num_layers (solvers.py:44)")
+  cfg = FlowConfig(dim=int(event_shape[0]), num_layers=int(num_layers),
+                   hidden_size=int(hidden_sizes[0]), mlp_num_layers=len(hidden_sizes),
+                   num_bins=int(num_bins))
+  return FlowModel(cfg)

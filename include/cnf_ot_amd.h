@@ -1,0 +1,137 @@
+/*
+ * cnf_ot_amd.h -- C ABI of the MI355X-native conditional RQS flow engine.
+ *
+ * This is the drop-in boundary for cnf_ot's flow-model call surface: the
+ * namedtuple of pure functions returned by RQSFlow(...) and wrapped by
+ * hk.multi_transform (reference: cnf_ot/models/flows.py:213-226, consumed by
+ * cnf_ot/mfc/applications.py and cnf_ot/mfc/solvers.py:48-53).  Every entry
+ * point below names the reference interface it replaces.  The reference is
+ * pure Python (no FFI of its own): the binding a maintainer would add is the
+ * ctypes stub shown in INTEGRATION.md; cnf_ot_amd/_capi.py is that stub.
+ *
+ * Conventions
+ *  - plain C types only; all tensor arguments are DEVICE pointers to
+ *    contiguous row-major float32 unless a parameter says otherwise;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *    every compute entry point only enqueues work on that stream: no
+ *    allocation, no synchronisation, graph-capturable;
+ *  - return value: 0 on success, negative CNF_ERR_* otherwise; nothing throws;
+ *  - a CnfModel may be used from several host threads as long as each uses its
+ *    own stream and nobody calls cnf_model_set_params concurrently.
+ *
+ * Condition argument (`c`, `c_block`): the condition of sample i is
+ * c[i / c_block].  c_block == 1 is the per-sample form the reference uses for
+ * sampling (cond[B,1] under vmap, conditional.py:400); c_block >= B is the
+ * broadcast form it uses for log_prob (cond[1], autoregressive.py:96);
+ * c_block == slice length fuses many time-slices into one launch (the shape of
+ * cnf_ot/utils.py:311-340).
+ */
+#ifndef CNF_OT_AMD_H
+#define CNF_OT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNF_OK 0
+#define CNF_ERR_INVALID (-22)     /* bad argument / shape               */
+#define CNF_ERR_UNSUPPORTED (-95) /* config has no compiled kernel      */
+#define CNF_ERR_NOMEM (-12)
+#define CNF_ERR_HIP (-5)          /* a HIP runtime call failed          */
+
+/* Network configuration: RQSFlow(event_shape=(dim,), num_layers,
+ * hidden_sizes=[hidden_size]*mlp_num_layers, num_bins) -- flows.py:178-199,
+ * solvers.py:41-47; keys of config/mfc.yaml:29-33.  Spline constants are the
+ * ones flows.py:124-132 passes to distrax.RationalQuadraticSpline. */
+typedef struct CnfConfig {
+  int32_t dim;            /* D: general.dim                         */
+  int32_t num_layers;     /* L: cnf.flow_num_layers                 */
+  int32_t hidden_size;    /* H: cnf.hidden_size                     */
+  int32_t mlp_num_layers; /* M: cnf.mlp_num_layers (>= 1)           */
+  int32_t num_bins;       /* K: cnf.num_bins                        */
+  float range_min;        /* -10  (flows.py:127)                    */
+  float range_max;        /* +10  (flows.py:128)                    */
+  float min_bin_size;     /* 1e-4 (distrax default)                 */
+  float min_knot_slope;   /* 1e-4 (flows.py:130)                    */
+} CnfConfig;
+
+typedef struct CnfModel CnfModel;
+
+/* Fills the reference's defaults (config/mfc.yaml:29-33, flows.py:124-132). */
+void cnf_config_default(CnfConfig *cfg, int32_t dim);
+
+/* Number of float32 parameters of the flat layout below; < 0 on bad config.
+ * 1 200 at dim=2, 11 824 at dim=10 (solvers.py:135-136 prints this count).
+ *
+ * Flat layout = haiku parameter tree in creation order (flows.py:46-86,
+ * 146-158):  first[P]   then for l in 0..L-1, d in 1..D-1:
+ *   mlp_layer{l}_d{d}/~/linear_0 w[(1+d)][H], b[H]; .../linear_{m} w[H][H],
+ *   b[H] (m=1..M-1); linear_out_layer{l}_d{d} w[H][P], b[P];   P = 3K+1. */
+int64_t cnf_param_count(const CnfConfig *cfg);
+
+/* Replaces: RQSFlow(...) + hk.multi_transform (flows.py:178-226,
+ * solvers.py:41-48).  Allocates the model's private device buffer (prepared
+ * `first` knot table + a copy of the conditioner weights) on the current
+ * device.  CNF_ERR_UNSUPPORTED if no kernel is compiled for (D,H,K). */
+int cnf_model_create(const CnfConfig *cfg, CnfModel **out);
+void cnf_model_destroy(CnfModel *m);
+
+/* Replaces: passing `params` to model.apply.* (pure-function convention,
+ * applications.py:85,153-158,233-239).  `params` is a device pointer to
+ * cnf_param_count() float32 in the flat layout; enqueues a small kernel that
+ * normalises the shared, condition-independent `first` spline once (float64
+ * on device) and snapshots the weights.  Must precede compute calls; call
+ * again after every optimiser step. */
+int cnf_model_set_params(CnfModel *m, const float *params, void *stream);
+
+/* Replaces: model.apply.forward(params, x, c) = flow.bijector.forward, and
+ * flow.bijector.forward_and_log_det (flows.py:221-223, conditional.py:233-237,
+ * 169-177; autoregressive.py:109-136).  base -> data.  y [B,D]; logdet [B]
+ * may be NULL. */
+int cnf_forward_logdet(CnfModel *m, const float *x, const float *c,
+                       int64_t c_block, float *y, float *logdet, int64_t B,
+                       void *stream);
+
+/* Replaces: model.apply.inverse(params, y, c) = flow.bijector.inverse /
+ * inverse_and_log_det (conditional.py:239-243,159-167;
+ * autoregressive.py:76-107).  data -> base.  logdet may be NULL. */
+int cnf_inverse_logdet(CnfModel *m, const float *y, const float *c,
+                       int64_t c_block, float *x, float *logdet, int64_t B,
+                       void *stream);
+
+/* Replaces: model.apply.log_prob(params, value, cond)
+ * (conditional.py:316-321; call sites applications.py:85,272). */
+int cnf_log_prob(CnfModel *m, const float *value, const float *c,
+                 int64_t c_block, float *logp, int64_t B, void *stream);
+
+/* Replaces: model.apply.sample / sample_and_log_prob(params, cond=, seed=,
+ * sample_shape=(B,)) (conditional.py:323-402; call sites
+ * applications.py:153-158,233-239, utils.py:330-336) for base noise the caller
+ * supplies (noise [B,D] ~ N(0,I), e.g. from cnf_fill_normal).  y [B,D];
+ * logp [B] may be NULL (= sample).  THE METRIC KERNEL of BASELINE.json. */
+int cnf_sample_logprob(CnfModel *m, const float *noise, const float *c,
+                       int64_t c_block, float *y, float *logp, int64_t B,
+                       void *stream);
+
+/* Replaces: the base draw `Independent(Normal(0,1)).sample(seed=rng, B)`
+ * (conditional.py:378,399).  JAX's threefry stream cannot be reproduced
+ * (JAX absent, stream version-dependent); the build's stream is
+ * Philox4x32-10 + Box-Muller, a pure function of (seed, element index):
+ * out[i] = normal(seed, first_element + i).  Sharding a batch over GPUs with
+ * first_element = rank_offset * D gives results independent of the GPU count. */
+int cnf_fill_normal(uint64_t seed, uint64_t first_element, int64_t n,
+                    float *out, void *stream);
+
+const char *cnf_strerror(int code);
+/* "gfx950" etc.: the offload arch this library was compiled for. */
+const char *cnf_build_arch(void);
+/* 1 if a kernel is compiled for this (dim, hidden_size, num_bins). */
+int cnf_config_supported(const CnfConfig *cfg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNF_OT_AMD_H */

@@ -1,0 +1,276 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the
+float64 oracle and the committed golden vectors.
+
+Tolerances (fp32 kernels vs float64 oracle; DESIGN.md "Numerics" derives them):
+  base -> data  (forward / sample / sample_and_log_prob):
+      |dy| <= 2e-5, |d logdet|, |d log_prob| <= 1e-5   (BASELINE.json's bar)
+  data -> base  (inverse / log_prob):
+      |dx| <= 2e-5, |d log_prob| <= 5e-5 max and <= 2e-5 at the 99.9th
+      percentile: the base term -x^2/2 multiplies the ~2e-6 position error of
+      a 20-wide fp32 knot table by |x| <= 5.
+These hold on the well-conditioned parameter sets (zeros; N(0, s^2) with the s
+recorded in each fixture).  The scale-0.5 `wild` set has local slopes up to
+e^16: no fp32 evaluation can meet an absolute bound there, so the kernel is
+required to be at least as accurate as the plain fp32 C port of the oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL_Y = 2e-5
+TOL_LD = 1e-5
+TOL_LP_SAMPLE = 1e-5
+TOL_LP_DATA_MAX = 5e-5
+TOL_LP_DATA_P999 = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+  assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+  return torch.device("cuda", 0)
+
+
+def _cfg_pair(D=2, L=2, H=16, M=2, K=5):
+  import oracle
+  from cnf_ot_amd import FlowConfig
+  return (FlowConfig(dim=D, num_layers=L, hidden_size=H, mlp_num_layers=M, num_bins=K),
+          oracle.OracleConfig(D=D, L=L, H=H, M=M, K=K))
+
+
+def _engine(fcfg, params64, dev):
+  from cnf_ot_amd import FlowEngine
+  eng = FlowEngine(fcfg, dev)
+  eng.load(torch.from_numpy(np.asarray(params64, dtype=np.float32)).to(dev))
+  return eng
+
+
+def _t(a, dev):
+  return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(dev)
+
+
+RTOL = 2.5e-7   # ~2 fp32 ulps: only matters where |value| >> 1 (tail samples, |log_prob| ~ 700)
+
+
+def _err(gpu, ref):
+  """|gpu - ref| with the fp32 representation floor of large values removed:
+  err = max(0, |d| - RTOL*|ref|)."""
+  d = np.abs(gpu.detach().cpu().numpy().astype(np.float64) - ref)
+  return np.maximum(d - RTOL * np.abs(ref), 0.0)
+
+
+GOLDEN = {
+  "flow_d1.npz": dict(D=1),
+  "flow_d2.npz": dict(D=2),
+  "flow_d10.npz": dict(D=10),
+  "flow_d3_k8_h32_m3_l3.npz": dict(D=3, L=3, H=32, M=3, K=8),
+}
+
+
+@pytest.mark.parametrize("fast", [True, False], ids=["fastmath", "ocml"])
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_golden_vectors(golden_dir, dev, name, fast):
+  fcfg, _ = _cfg_pair(**GOLDEN[name])
+  g = np.load(os.path.join(golden_dir, name))
+  eng = _engine(fcfg, g["params"], dev)
+  eng.set_fast_math(fast)
+  x = _t(g["noise"], dev)
+  for tag, c in (("u", g["c_uniform"]), ("p", g["c_per"])):
+    ct = _t(c, dev)
+    y, fldj = eng.forward_logdet(x, ct)
+    assert _err(y, g[f"y_{tag}"]).max() <= TOL_Y
+    assert _err(fldj, g[f"fldj_{tag}"]).max() <= TOL_LD
+    y2, lp = eng.sample_logprob(x, ct)
+    assert torch.equal(y, y2)
+    assert _err(lp, g[f"lp_sample_{tag}"]).max() <= TOL_LP_SAMPLE
+    # data -> base on the oracle's (float32-rounded) samples
+    y_in = g[f"y_{tag}"].astype(np.float32)
+    import oracle
+    _, ocfg = _cfg_pair(**GOLDEN[name])
+    xb_ref, ildj_ref = oracle.inverse_logdet(ocfg, g["params"], y_in.astype(np.float64), c)
+    lp_ref = oracle.log_prob(ocfg, g["params"], y_in.astype(np.float64), c)
+    xb, ildj = eng.inverse_logdet(_t(y_in, dev), ct)
+    assert _err(xb, xb_ref).max() <= TOL_Y
+    assert _err(ildj, ildj_ref).max() <= TOL_LD * 2
+    assert _err(eng.log_prob(_t(y_in, dev), ct), lp_ref).max() <= TOL_LP_DATA_MAX
+  lpv = eng.log_prob(_t(g["value"], dev), _t(g["c_uniform"], dev))
+  assert _err(lpv, g["lp_value_u"]).max() <= TOL_LP_DATA_MAX
+
+
+@pytest.mark.parametrize("params_kind", ["zeros", "random"])
+@pytest.mark.parametrize("t", [0.0, 0.5, 1.0])
+def test_config2_batch_65536_vs_oracle(dev, params_kind, t):
+  """BASELINE config 2 / SURVEY.md 8(d): D=2, B=65 536, base noise N(0,I), c
+  uniform t in {0, .5, 1}; params (i) zeros (identity), (ii) N(0, 0.2^2) seed 42."""
+  import oracle
+  fcfg, ocfg = _cfg_pair(D=2)
+  rng = np.random.default_rng(42)
+  n = oracle.param_count(ocfg)
+  params = np.zeros(n) if params_kind == "zeros" else rng.normal(0, 0.2, n).astype(np.float32).astype(np.float64)
+  noise = rng.normal(size=(65536, 2)).astype(np.float32)
+  eng = _engine(fcfg, params, dev)
+  y, lp = eng.sample_logprob(_t(noise, dev), torch.tensor([t], device=dev))
+  y_ref, lp_ref = oracle.sample_logprob(ocfg, params, noise.astype(np.float64), [t])
+  ey, elp = _err(y, y_ref), _err(lp, lp_ref)
+  print(f"\n[cfg2 {params_kind} t={t}] max|dy|={ey.max():.2e} max|dlogp|={elp.max():.2e} "
+        f"p99.9={np.quantile(elp, 0.999):.2e} median={np.median(elp):.2e}")
+  assert ey.max() <= TOL_Y
+  assert elp.max() <= TOL_LP_SAMPLE
+  if params_kind == "zeros":       # identity at init (flows.py:48,71-76): fp32 rounding only
+    assert (y.cpu() - torch.from_numpy(noise)).abs().max().item() <= 1e-6
+  # log_prob direction on the kernel's own samples
+  y32 = y.cpu().numpy()
+  lpd_ref = oracle.log_prob(ocfg, params, y32.astype(np.float64), [t])
+  elpd = _err(eng.log_prob(y, torch.tensor([t], device=dev)), lpd_ref)
+  print(f"[cfg2 {params_kind} t={t}] log_prob dir: max={elpd.max():.2e} p99.9={np.quantile(elpd, 0.999):.2e}")
+  assert elpd.max() <= TOL_LP_DATA_MAX and np.quantile(elpd, 0.999) <= TOL_LP_DATA_P999
+
+
+def test_dim10_batch_vs_oracle(dev):
+  """BASELINE config 4 shape: D=10 (per-GPU shard 32 768), N(0, 0.12^2) params."""
+  import oracle
+  fcfg, ocfg = _cfg_pair(D=10)
+  rng = np.random.default_rng(4)
+  params = rng.normal(0, 0.12, oracle.param_count(ocfg)).astype(np.float32).astype(np.float64)
+  noise = rng.normal(size=(32768, 10)).astype(np.float32)
+  eng = _engine(fcfg, params, dev)
+  y, lp = eng.sample_logprob(_t(noise, dev), torch.tensor([0.3], device=dev))
+  y_ref, lp_ref = oracle.sample_logprob(ocfg, params, noise.astype(np.float64), [0.3])
+  print(f"\n[d10] max|dy|={_err(y, y_ref).max():.2e} max|dlogp|={_err(lp, lp_ref).max():.2e}")
+  assert _err(y, y_ref).max() <= TOL_Y
+  assert _err(lp, lp_ref).max() <= 2e-5      # 20 splines summed instead of 4
+
+
+def test_wild_params_no_worse_than_fp32_port(dev, golden_dir):
+  """SURVEY.md 8(d) cfg 2 (ii) literal: N(0, 0.5^2) on every tensor, seed 42."""
+  import oracle
+  fcfg, ocfg = _cfg_pair(D=2)
+  rng = np.random.default_rng(42)
+  params = rng.normal(0, 0.5, oracle.param_count(ocfg)).astype(np.float32)
+  noise = rng.normal(size=(65536, 2)).astype(np.float32)
+  eng = _engine(fcfg, params, dev)
+  _, lp = eng.sample_logprob(_t(noise, dev), torch.tensor([0.5], device=dev))
+  _, lp64 = oracle.sample_logprob(ocfg, params.astype(np.float64), noise.astype(np.float64), [0.5])
+  _, lp32 = oracle.sample_logprob(ocfg, params, noise, [0.5], dtype=np.float32)
+  e_gpu, e_port = _err(lp, lp64), np.abs(lp32.astype(np.float64) - lp64)
+  print(f"\n[wild] gpu: median={np.median(e_gpu):.2e} p99={np.quantile(e_gpu, .99):.2e} max={e_gpu.max():.2e} | "
+        f"fp32 C port: median={np.median(e_port):.2e} p99={np.quantile(e_port, .99):.2e} max={e_port.max():.2e}")
+  assert np.median(e_gpu) <= 2 * np.median(e_port) + 1e-6
+  assert np.quantile(e_gpu, 0.99) <= 2 * np.quantile(e_port, 0.99) + 1e-5
+
+
+def test_roundtrip_and_consistency_at_full_size(dev):
+  """Size-independent properties at BASELINE sizes (no oracle needed):
+  inverse(forward(x)) == x, logdets antisymmetric, log_prob(sample) equals the
+  log_prob returned with the sample."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  for D, B, scale in ((2, 1 << 20, 0.2), (10, 262144, 0.12)):
+    cfg = FlowConfig(dim=D)
+    eng = FlowEngine(cfg, dev).load(Params.random(cfg, scale, seed=7, device=dev))
+    x = eng.normal(123, B)
+    c = torch.tensor([0.6], device=dev)
+    y, fldj = eng.forward_logdet(x, c)
+    xb, ildj = eng.inverse_logdet(y, c)
+    assert (xb - x).abs().max().item() <= 1e-4
+    assert (fldj + ildj).abs().max().item() <= 1e-4
+    _, lp_s = eng.sample_logprob(x, c)
+    assert (eng.log_prob(y, c) - lp_s).abs().max().item() <= 2e-4
+    assert torch.isfinite(y).all() and torch.isfinite(lp_s).all()
+
+
+def test_condition_layouts_agree(dev):
+  """uniform / per-sample / per-slice / ragged c_block forms give the same
+  numbers, and tails + ragged batch sizes are handled."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  cfg = FlowConfig(dim=2)
+  eng = FlowEngine(cfg, dev).load(Params.random(cfg, 0.2, seed=3, device=dev))
+  S, Bs = 6, 768                       # 6 slices of 768 (multiple of the 256 tile)
+  x = eng.normal(5, S * Bs)
+  ts = torch.linspace(0, 1, S, device=dev)
+  y_sl, lp_sl = eng.sample_logprob(x, ts)                              # c_block = 768
+  y_ps, lp_ps = eng.sample_logprob(x, ts.repeat_interleave(Bs)[:, None])   # per sample
+  assert torch.equal(y_sl, y_ps) and torch.equal(lp_sl, lp_ps)
+  for s in range(S):
+    y_u, lp_u = eng.sample_logprob(x[s * Bs:(s + 1) * Bs], ts[s:s + 1])
+    assert torch.equal(y_u, y_sl[s * Bs:(s + 1) * Bs]) and torch.equal(lp_u, lp_sl[s * Bs:(s + 1) * Bs])
+  # ragged: 5 slices of 100 (not a multiple of the tile) -> generic c_block path
+  xr = x[:500]
+  tr = torch.linspace(0.1, 0.9, 5, device=dev)
+  y_r, lp_r = eng.sample_logprob(xr, tr)
+  y_r2, lp_r2 = eng.sample_logprob(xr, tr.repeat_interleave(100))
+  assert torch.equal(y_r, y_r2) and torch.equal(lp_r, lp_r2)
+  # B = 1 and B = 257 (partial tiles)
+  for B in (1, 257):
+    yb, lpb = eng.sample_logprob(x[:B], ts[:1])
+    assert torch.equal(yb, y_sl[:B]) and torch.equal(lpb, lp_sl[:B])
+
+
+def test_empty_batch_and_errors(dev):
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  from cnf_ot_amd._capi import CnfError
+  cfg = FlowConfig(dim=2)
+  eng = FlowEngine(cfg, dev)
+  with pytest.raises(CnfError):      # params not set yet
+    eng.log_prob(torch.zeros(4, 2, device=dev), torch.zeros(1, device=dev))
+  eng.load(Params.zeros(cfg, dev))
+  y, lp = eng.sample_logprob(torch.zeros(0, 2, device=dev), torch.zeros(1, device=dev))
+  assert y.shape == (0, 2) and lp.shape == (0,)
+  with pytest.raises(ValueError):
+    eng.log_prob(torch.zeros(4, 3, device=dev), torch.zeros(1, device=dev))
+  with pytest.raises(ValueError):
+    eng.log_prob(torch.zeros(4, 2, device=dev), torch.zeros(3, device=dev))
+  with pytest.raises(CnfError):
+    FlowEngine(FlowConfig(dim=2, hidden_size=17), dev)
+
+
+def test_philox_normals_match_oracle_stream(dev):
+  import oracle
+  from cnf_ot_amd import FlowConfig, FlowEngine
+  eng = FlowEngine(FlowConfig(dim=2), dev)
+  z = eng.normal(42, 50001).cpu().numpy().reshape(-1)
+  ref = oracle.normal(42, 0, z.size)
+  assert np.abs(z - ref).max() <= 2e-5
+  # element-indexed: a shard that starts at sample 1001 reproduces the same values
+  z2 = eng.normal(42, 3000, first_sample=1001).cpu().numpy().reshape(-1)
+  assert np.array_equal(z2, z[2002:2002 + 6000])
+  z3 = eng.normal((42, 1001), 3000).cpu().numpy().reshape(-1)
+  assert np.array_equal(z3, z2)
+  # D=3: shards that do not start on a 4-element Philox block
+  eng3 = FlowEngine(FlowConfig(dim=3), dev)
+  w = eng3.normal(9, 1000).cpu().numpy().reshape(-1)
+  assert np.abs(w - oracle.normal(9, 0, 3000)).max() <= 2e-5
+  assert np.array_equal(eng3.normal(9, 100, first_sample=333).cpu().numpy().reshape(-1), w[999:1299])
+
+
+def test_reference_call_surface(dev):
+  """The calls cnf_ot/mfc/applications.py makes, verbatim in shape."""
+  import oracle
+  from cnf_ot_amd import RQSFlow, Params
+  model = RQSFlow(event_shape=(2,), num_layers=2, hidden_sizes=[16] * 2, num_bins=5, periodized=False)
+  params = model.init(0, torch.zeros(1, 2), torch.zeros(1))
+  assert params.flat.is_cuda
+  B = 4096
+  # applications.py:226-239: same seed => same base noise at two conditions
+  cond1 = torch.ones(B, 1, device=dev) * 0.495
+  r1 = model.apply.sample(params, seed=7, sample_shape=(B,), cond=cond1)
+  r2 = model.apply.sample(params, seed=7, sample_shape=(B,), cond=cond1 + 0.01)
+  assert r1.shape == (B, 2) and torch.equal(r1, r2)          # identity flow ignores c
+  # applications.py:153-158
+  s, lp = model.apply.sample_and_log_prob(params, cond=cond1, seed=7, sample_shape=(B,))
+  assert torch.equal(s, r1) and lp.shape == (B,)
+  # applications.py:85: log_prob(params, samples, cond=ones(1)*c)
+  lp2 = model.apply.log_prob(params, s, cond=torch.ones(1, device=dev) * 0.495)
+  ref = (-0.5 * s.double() ** 2 - 0.5 * np.log(2 * np.pi)).sum(1)
+  assert (lp2.double() - ref).abs().max().item() <= 1e-5
+  assert (lp.double() - ref).abs().max().item() <= 1e-5
+  # utils.py:619,627: forward / inverse
+  p2 = Params.random(model.cfg, 0.2, seed=1, device=dev)
+  y = model.apply.forward(p2, s, torch.ones(1, device=dev) * 0.3)
+  xb = model.apply.inverse(p2, y, torch.ones(1, device=dev) * 0.3)
+  assert (xb - s).abs().max().item() <= 5e-5
+  ocfg = oracle.OracleConfig(D=2)
+  y_ref, _ = oracle.forward_logdet(ocfg, p2.flat.cpu().double().numpy(), s.cpu().double().numpy(), [0.3])
+  assert _err(y, y_ref).max() <= TOL_Y
