@@ -51,6 +51,7 @@ SYMBOLS = {
 # internal knobs (not part of the public header)
 _INTERNAL = {
   "cnf_model_set_fast_math": (ctypes.c_int, [_P, ctypes.c_int]),
+  "cnf_model_set_samples_per_lane": (ctypes.c_int, [_P, ctypes.c_int]),
 }
 
 _lib = None

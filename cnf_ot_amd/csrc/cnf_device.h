@@ -3,6 +3,15 @@
 // table (LDS gather) and from per-lane conditioner output (registers), and the
 // time-conditioned MLP conditioner with wave-uniform weights.
 //
+// Everything is templated on the per-lane value type T:
+//   T = float : one sample per lane;
+//   T = v2f   : two samples per lane in a 64-bit register pair, so the bulk of
+//               the arithmetic issues as packed fp32 (v_pk_fma_f32 /
+//               v_pk_mul_f32 / v_pk_add_f32).  A wave64 VALU instruction
+//               occupies the SIMD for 4 cycles on gfx950 (measured:
+//               profiles/r01a, SQ_ACTIVE_INST_VALU = 100 % at 4.1 cycles per
+//               instruction), so only packed math reaches the fp32 peak.
+//
 // Reference behaviour restated (never copied; the reference is Python/JAX):
 //   spline       distrax.RationalQuadraticSpline, call site flows.py:124-132
 //                (algorithm: SURVEY.md Appendix A)
@@ -12,8 +21,12 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace cnf {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 
 // Pointer into the AMDGPU constant address space (4).  Global and constant
 // addresses coincide; a load through this type from a wave-uniform address is
@@ -24,9 +37,7 @@ namespace cnf {
 // are not clobbered.)  The prepared buffer is never written by a flow kernel.
 typedef const float __attribute__((address_space(4)))* uniform_ptr;
 
-__device__ __forceinline__ uniform_ptr as_uniform(const float* p) {
-  return (uniform_ptr)p;
-}
+__device__ __forceinline__ uniform_ptr as_uniform(const float* p) { return (uniform_ptr)p; }
 
 // Constant-address-space loads are `invariant`: LICM hoists every weight load
 // of the kernel out of the tile loop (1 184 SGPRs at D=2 -> spilled to VGPR
@@ -39,22 +50,27 @@ __device__ __forceinline__ uniform_ptr launder(uniform_ptr p) {
 
 // ---------------------------------------------------------------------------
 // Prepared model buffer (device, float32), written by prepare_kernel:
-//   [0, K*ROW)                 K rows of the `first` spline, one per bin
-//   [KNOT_X, +K+1) [KNOT_Y, +K+1)   knot positions for the bin search
-//   [TAIL, +6)                 d_lo, d_hi, log d_lo, log d_hi, 1/d_lo, 1/d_hi
-//   [hdr_floats(K), ...)       conditioner weights, flat layout of the C ABI
+//   [F * KP + k]   field F of bin k of the `first` spline, F in TabField,
+//                  KP = tab_stride(K) (structure-of-arrays: a lane gathers each
+//                  field with one ds_read_b32 straight into the register it is
+//                  used from)
+//   [hdr_floats(K), ...)   conditioner weights, flat layout of the C ABI
 // The `first` spline is shared by every layer and ignores c (flows.py:47-55,
 // autoregressive.py:88-92), so it is normalised ONCE per parameter set, in
 // float64, instead of once per sample per layer.
 // ---------------------------------------------------------------------------
-constexpr int ROW = 12;
-enum { R_X0 = 0, R_Y0, R_BW, R_BH, R_IBW, R_IBH, R_S, R_ST, R_D0, R_D1, R_L2S, R_PAD };
-
-__host__ __device__ constexpr int knot_x_off(int K) { return K * ROW; }
-__host__ __device__ constexpr int knot_y_off(int K) { return K * ROW + (K + 1); }
-__host__ __device__ constexpr int tail_off(int K) { return K * ROW + 2 * (K + 1); }
-__host__ __device__ constexpr int hdr_floats(int K) { return (tail_off(K) + 6 + 3) & ~3; }
+enum TabField {
+  F_X0 = 0, F_Y0, F_BW, F_BH, F_IBW, F_IBH, F_S, F_ST, F_D0, F_D1, F_L2S,
+  F_XK,      // x knots [K+1]
+  F_YK,      // y knots [K+1]
+  F_TAIL,    // d_lo, d_hi, log d_lo, log d_hi, 1/d_lo, 1/d_hi
+  F_COUNT
+};
 enum { T_DLO = 0, T_DHI, T_LOG_DLO, T_LOG_DHI, T_INV_DLO, T_INV_DHI };
+
+__host__ __device__ constexpr int tab_stride(int K) { return K + 1 < 6 ? 6 : K + 1; }
+__host__ __device__ constexpr int tab_off(int field, int K) { return field * tab_stride(K); }
+__host__ __device__ constexpr int hdr_floats(int K) { return (F_COUNT * tab_stride(K) + 3) & ~3; }
 
 struct SplineConsts {
   float lo, hi;        // range_min, range_max
@@ -65,10 +81,51 @@ struct SplineConsts {
 };
 
 // ---------------------------------------------------------------------------
+// Elementwise helpers over T in {float, v2f}
+// ---------------------------------------------------------------------------
+template <class T> struct Lanes;
+template <> struct Lanes<float> { static constexpr int N = 1; typedef int index; };
+template <> struct Lanes<v2f> { static constexpr int N = 2; typedef v2i index; };
+
+template <class T> __device__ __forceinline__ T splat(float a);
+template <> __device__ __forceinline__ float splat<float>(float a) { return a; }
+template <> __device__ __forceinline__ v2f splat<v2f>(float a) { return v2f{a, a}; }
+
+__device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f vfma(float a, v2f b, v2f c) { return __builtin_elementwise_fma(v2f{a, a}, b, c); }
+__device__ __forceinline__ v2f vfma(v2f a, float b, v2f c) { return __builtin_elementwise_fma(a, v2f{b, b}, c); }
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, float c) { return __builtin_elementwise_fma(a, b, v2f{c, c}); }
+
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ v2f vmax(v2f a, v2f b) { return v2f{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+__device__ __forceinline__ float vabs(float a) { return fabsf(a); }
+__device__ __forceinline__ v2f vabs(v2f a) { return v2f{fabsf(a.x), fabsf(a.y)}; }
+__device__ __forceinline__ float vrelu(float a) { return fmaxf(a, 0.0f); }
+__device__ __forceinline__ v2f vrelu(v2f a) { return v2f{fmaxf(a.x, 0.0f), fmaxf(a.y, 0.0f)}; }
+__device__ __forceinline__ float clip01(float z) { return fminf(fmaxf(z, 0.0f), 1.0f); }
+__device__ __forceinline__ v2f clip01(v2f z) { return v2f{clip01(z.x), clip01(z.y)}; }
+
+__device__ __forceinline__ bool vge(float a, float b) { return a >= b; }
+__device__ __forceinline__ v2i vge(v2f a, v2f b) { return a >= b; }
+__device__ __forceinline__ v2i vge(v2f a, float b) { return a >= v2f{b, b}; }
+__device__ __forceinline__ bool vle(float a, float b) { return a <= b; }
+__device__ __forceinline__ v2i vle(v2f a, float b) { return a <= v2f{b, b}; }
+__device__ __forceinline__ bool vlt(float a, float b) { return a < b; }
+__device__ __forceinline__ v2i vlt(v2f a, float b) { return a < v2f{b, b}; }
+
+__device__ __forceinline__ float vsel(bool m, float a, float b) { return m ? a : b; }
+__device__ __forceinline__ v2f vsel(v2i m, v2f a, v2f b) { return v2f{m.x ? a.x : b.x, m.y ? a.y : b.y}; }
+__device__ __forceinline__ bool vany(bool m) { return m; }
+__device__ __forceinline__ bool vany(v2i m) { return (m.x | m.y) != 0; }
+
+// ---------------------------------------------------------------------------
 // Math policy.  FAST=false: ocml expf/logf/sqrtf and IEEE division.
 // FAST=true: hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32 /
-// v_sqrt_f32, 1 ulp each) with the exp argument scaled in two pieces so the
-// result keeps ~1 ulp for |x| up to ~80.
+// v_sqrt_f32, 1 ulp each); the scalings around them are packed for v2f.
+// exp(x) = 2^(x*log2 e): the product's rounding costs |x| * 6e-8 relative,
+// which only matters for terms that are negligible anyway (softmax terms far
+// below the maximum, softplus arguments far from 0).
 // ---------------------------------------------------------------------------
 template <bool FAST> struct Math;
 
@@ -78,118 +135,145 @@ template <> struct Math<false> {
   static __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
   static __device__ __forceinline__ float div(float a, float b) { return a / b; }
   static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
+  static __device__ __forceinline__ v2f exp(v2f x) { return v2f{expf(x.x), expf(x.y)}; }
+  static __device__ __forceinline__ v2f log(v2f x) { return v2f{logf(x.x), logf(x.y)}; }
+  static __device__ __forceinline__ v2f rcp(v2f x) { return v2f{1.0f / x.x, 1.0f / x.y}; }
+  static __device__ __forceinline__ v2f div(v2f a, v2f b) { return v2f{a.x / b.x, a.y / b.y}; }
+  static __device__ __forceinline__ v2f sqrt(v2f x) { return v2f{sqrtf(x.x), sqrtf(x.y)}; }
 };
 
+constexpr float LOG2E = 1.44269502162933349609375f;
+constexpr float LN2 = 0.693147182464599609375f;
+
 template <> struct Math<true> {
-  static __device__ __forceinline__ float exp(float x) {
-    const float L2E_HI = 1.44269502162933349609375f;     // fl(log2 e)
-    const float L2E_LO = 1.925963033500011e-08f;         // log2 e - fl(log2 e)
-    float hi = x * L2E_HI;
-    float lo = fmaf(x, L2E_HI, -hi) + x * L2E_LO;        // exact product tail
-    float r = __builtin_amdgcn_exp2f(hi);
-    return fmaf(r, lo * 0.693147182464599609375f, r);    // 2^(hi+lo)
-  }
-  static __device__ __forceinline__ float log(float x) {
-    return __builtin_amdgcn_logf(x) * 0.693147182464599609375f;
-  }
+  static __device__ __forceinline__ float exp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }
+  static __device__ __forceinline__ float log(float x) { return __builtin_amdgcn_logf(x) * LN2; }
   static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
   static __device__ __forceinline__ float div(float a, float b) {
-    float r = __builtin_amdgcn_rcpf(b);
-    float q = a * r;
+    const float r = __builtin_amdgcn_rcpf(b), q = a * r;
     return fmaf(fmaf(-b, q, a), r, q);                   // one Newton step
   }
   static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+  static __device__ __forceinline__ v2f exp(v2f x) {
+    const v2f t = x * LOG2E;
+    return v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+  }
+  static __device__ __forceinline__ v2f log(v2f x) {
+    return v2f{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)} * LN2;
+  }
+  static __device__ __forceinline__ v2f rcp(v2f x) {
+    return v2f{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
+  }
+  static __device__ __forceinline__ v2f div(v2f a, v2f b) {
+    const v2f r = rcp(b), q = a * r;
+    return vfma(vfma(-b, q, a), r, q);
+  }
+  static __device__ __forceinline__ v2f sqrt(v2f x) {
+    return v2f{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
+  }
 };
 
-__device__ __forceinline__ float clip01(float z) { return fminf(fmaxf(z, 0.0f), 1.0f); }
-
 // softplus(t + offset) + m  (distrax _normalize_knot_slopes)
-template <bool FAST>
-__device__ __forceinline__ float knot_slope(float t, const SplineConsts& sc) {
-  float v = t + sc.sp_offset;
-  float e = Math<FAST>::exp(-fabsf(v));
-  // log1p(e), e in (0,1]: log(1+e) loses nothing that matters in absolute
-  // terms (the slope is O(1)); keep the small-e branch exact to first order.
-  // (both forms are evaluated and selected: a branch here splits the wave's
-  // straight-line code and lets the compiler sink work into it)
-  const float l_log = Math<FAST>::log(1.0f + e);
-  const float l_ser = fmaf(-0.5f * e, e, e);
-  const float l = e < 1e-4f ? l_ser : l_log;
-  return fmaxf(v, 0.0f) + l + sc.min_slope;
+template <bool FAST, class T>
+__device__ __forceinline__ T knot_slope(T t, const SplineConsts& sc) {
+  const T v = t + sc.sp_offset;
+  const T e = Math<FAST>::exp(-vabs(v));
+  // log1p(e), e in (0,1].  Both forms are evaluated and selected: a branch
+  // here would split the wave's straight-line code.
+  const T l_log = Math<FAST>::log(e + 1.0f);
+  const T l_ser = vfma(e * -0.5f, e, e);
+  const T l = vsel(vlt(e, 1e-4f), l_ser, l_log);
+  return vrelu(v) + l + sc.min_slope;
 }
 
 // Shared tail of both directions: from the selected bin to (out, logdet).
 // INV=false: distrax _rational_quadratic_spline_fwd; INV=true: ..._inv.
-template <bool INV, bool FAST>
-__device__ __forceinline__ void rqs_bin_eval(float v, float x0, float y0, float bw, float bh,
-                                             float ibw, float ibh, float s, float st,
-                                             float d0, float d1, float l2s,
-                                             float& out, float& ld) {
+template <bool INV, bool FAST, class T>
+__device__ __forceinline__ void rqs_bin_eval(T v, T x0, T y0, T bw, T bh, T ibw, T ibh, T s, T st,
+                                             T d0, T d1, T l2s, T& out, T& ld) {
   using M = Math<FAST>;
-  float z;
+  T z;
   if (INV) {
-    float w = clip01((v - y0) * ibh);
-    float c = -s * w;
-    float b = d0 - st * w;
-    float a = s - b;
-    float disc = fmaf(b, b, -4.0f * a * c);
-    z = clip01(M::div(-2.0f * c, b + M::sqrt(disc)));
-    out = fmaf(bw, z, x0);
+    const T w = clip01((v - y0) * ibh);
+    const T c = -s * w;
+    const T b = vfma(-st, w, d0);
+    const T a = s - b;
+    const T disc = vfma(b, b, a * c * -4.0f);
+    z = clip01(M::div(c * -2.0f, b + M::sqrt(disc)));
+    out = vfma(bw, z, x0);
   } else {
     z = clip01((v - x0) * ibw);
   }
-  float sq_z = z * z;
-  float z1mz = z - sq_z;
-  float omz = 1.0f - z;
-  float den = fmaf(st, z1mz, s);
-  float iden = M::rcp(den);
-  if (!INV) out = fmaf(bh * fmaf(s, sq_z, d0 * z1mz), iden, y0);
-  float num2 = fmaf(d1, sq_z, fmaf(2.0f * s, z1mz, d0 * omz * omz));
+  const T sq_z = z * z;
+  const T z1mz = z - sq_z;
+  const T omz = 1.0f - z;
+  const T den = vfma(st, z1mz, s);
+  const T iden = M::rcp(den);
+  if (!INV) out = vfma(bh * vfma(s, sq_z, d0 * z1mz), iden, y0);
+  const T num2 = vfma(d1, sq_z, vfma(s * 2.0f, z1mz, d0 * omz * omz));
   // 2 log s + log(num2) - 2 log(den) = l2s + log(num2 / den^2)
-  float ldf = l2s + M::log(num2 * iden * iden);
+  const T ldf = l2s + M::log(num2 * iden * iden);
   ld = INV ? -ldf : ldf;
 }
 
 // ---------------------------------------------------------------------------
-// Spline of the shared `first` parameters: per-lane bin index, LDS row gather.
-// `tab` points at the prepared header staged in LDS.
+// Spline of the shared `first` parameters: per-lane bin index, LDS gather of
+// the bin's pre-normalised constants.  `tab` is the prepared header in LDS.
 // ---------------------------------------------------------------------------
-template <int K, bool INV, bool FAST>
-__device__ __forceinline__ void table_spline(const float* tab, float v, const SplineConsts& sc,
-                                             float& out, float& ld) {
-  const float* pos = tab + (INV ? knot_y_off(K) : knot_x_off(K));
+template <int K> __device__ __forceinline__ int bin_of(const float* pos, float v) {
   int k = 0;
 #pragma unroll
   for (int j = 1; j < K; ++j) k += (v >= pos[j]) ? 1 : 0;
-  const float4* row = reinterpret_cast<const float4*>(tab + k * ROW);
-  float4 r0 = row[0], r1 = row[1], r2 = row[2];
-  rqs_bin_eval<INV, FAST>(v, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, out, ld);
-  const float* tl = tab + tail_off(K);
-  if (v <= sc.lo) {          // linear tails (rare: |v| >= 10)
-    out = INV ? fmaf(v - sc.lo, tl[T_INV_DLO], sc.lo) : fmaf(v - sc.lo, tl[T_DLO], sc.lo);
-    ld = INV ? -tl[T_LOG_DLO] : tl[T_LOG_DLO];
-  }
-  if (v >= sc.hi) {
-    out = INV ? fmaf(v - sc.hi, tl[T_INV_DHI], sc.hi) : fmaf(v - sc.hi, tl[T_DHI], sc.hi);
-    ld = INV ? -tl[T_LOG_DHI] : tl[T_LOG_DHI];
+  return k;
+}
+template <int K> __device__ __forceinline__ v2i bin_of(const float* pos, v2f v) {
+  return v2i{bin_of<K>(pos, v.x), bin_of<K>(pos, v.y)};
+}
+template <int K> __device__ __forceinline__ float gather(const float* tab, int f, int k) {
+  return tab[tab_off(f, K) + k];
+}
+template <int K> __device__ __forceinline__ v2f gather(const float* tab, int f, v2i k) {
+  return v2f{tab[tab_off(f, K) + k.x], tab[tab_off(f, K) + k.y]};
+}
+
+template <int K, bool INV, bool FAST, class T>
+__device__ __forceinline__ void table_spline(const float* tab, T v, const SplineConsts& sc, T& out, T& ld) {
+  const float* pos = tab + tab_off(INV ? F_YK : F_XK, K);
+  const typename Lanes<T>::index k = bin_of<K>(pos, v);
+  rqs_bin_eval<INV, FAST, T>(v, gather<K>(tab, F_X0, k), gather<K>(tab, F_Y0, k), gather<K>(tab, F_BW, k),
+                             gather<K>(tab, F_BH, k), gather<K>(tab, F_IBW, k), gather<K>(tab, F_IBH, k),
+                             gather<K>(tab, F_S, k), gather<K>(tab, F_ST, k), gather<K>(tab, F_D0, k),
+                             gather<K>(tab, F_D1, k), gather<K>(tab, F_L2S, k), out, ld);
+  const auto below = vle(v, sc.lo);
+  const auto above = vge(v, sc.hi);
+  if (vany(below) || vany(above)) {      // linear tails (rare: |v| >= 10)
+    const float* tl = tab + tab_off(F_TAIL, K);
+    const T lo_out = INV ? vfma(v - sc.lo, splat<T>(tl[T_INV_DLO]), splat<T>(sc.lo))
+                         : vfma(v - sc.lo, splat<T>(tl[T_DLO]), splat<T>(sc.lo));
+    const T hi_out = INV ? vfma(v - sc.hi, splat<T>(tl[T_INV_DHI]), splat<T>(sc.hi))
+                         : vfma(v - sc.hi, splat<T>(tl[T_DHI]), splat<T>(sc.hi));
+    out = vsel(below, lo_out, out);
+    ld = vsel(below, splat<T>(INV ? -tl[T_LOG_DLO] : tl[T_LOG_DLO]), ld);
+    out = vsel(above, hi_out, out);
+    ld = vsel(above, splat<T>(INV ? -tl[T_LOG_DHI] : tl[T_LOG_DHI]), ld);
   }
 }
 
 // ---------------------------------------------------------------------------
 // Spline whose 3K+1 parameters were just produced by the conditioner, one set
-// per lane, in registers.  The bin is selected with a compare/select chain
+// per sample, in registers.  The bin is selected with a compare/select chain
 // over the running knot (registers cannot be indexed per lane); only the two
 // slopes of the selected bin are normalised (2 softplus instead of K+1).
 // ---------------------------------------------------------------------------
-template <int K, bool INV, bool FAST>
-__device__ __forceinline__ void cond_spline(const float (&th)[3 * K + 1], float v,
-                                            const SplineConsts& sc, float& out, float& ld) {
+template <int K, bool INV, bool FAST, class T>
+__device__ __forceinline__ void cond_spline(const T (&th)[3 * K + 1], T v, const SplineConsts& sc,
+                                            T& out, T& ld) {
   using M = Math<FAST>;
-  float mw = th[0], mh = th[K];
+  T mw = th[0], mh = th[K];
 #pragma unroll
-  for (int k = 1; k < K; ++k) { mw = fmaxf(mw, th[k]); mh = fmaxf(mh, th[K + k]); }
-  float ew[K], eh[K];
-  float sw = 0.0f, sh = 0.0f;
+  for (int k = 1; k < K; ++k) { mw = vmax(mw, th[k]); mh = vmax(mh, th[K + k]); }
+  T ew[K], eh[K];
+  T sw = splat<T>(0.0f), sh = splat<T>(0.0f);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     ew[k] = M::exp(th[k] - mw);
@@ -197,53 +281,73 @@ __device__ __forceinline__ void cond_spline(const float (&th)[3 * K + 1], float 
     sw += ew[k];
     sh += eh[k];
   }
-  const float aw = sc.span_eff * M::rcp(sw), ah = sc.span_eff * M::rcp(sh);
-  float px = sc.lo, py = sc.lo;                 // running knot k
-  float wk = fmaf(ew[0], aw, sc.min_bin), hk = fmaf(eh[0], ah, sc.min_bin);
-  float x0 = px, y0 = py, bw = wk, bh = hk, t0 = th[2 * K], t1 = th[2 * K + 1];
+  const T aw = M::rcp(sw) * sc.span_eff, ah = M::rcp(sh) * sc.span_eff;
+  T px = splat<T>(sc.lo), py = splat<T>(sc.lo);          // running knot k
+  T wk = vfma(ew[0], aw, splat<T>(sc.min_bin)), hk = vfma(eh[0], ah, splat<T>(sc.min_bin));
+  T x0 = px, y0 = py, bw = wk, bh = hk, t0 = th[2 * K], t1 = th[2 * K + 1];
 #pragma unroll
   for (int k = 1; k < K; ++k) {
     px += wk;
     py += hk;
     if (k == K - 1) { wk = sc.hi - px; hk = sc.hi - py; }   // last knot is exactly hi
-    else { wk = fmaf(ew[k], aw, sc.min_bin); hk = fmaf(eh[k], ah, sc.min_bin); }
-    const bool ge = INV ? (v >= py) : (v >= px);
-    x0 = ge ? px : x0; y0 = ge ? py : y0;
-    bw = ge ? wk : bw; bh = ge ? hk : bh;
-    t0 = ge ? th[2 * K + k] : t0; t1 = ge ? th[2 * K + k + 1] : t1;
+    else { wk = vfma(ew[k], aw, splat<T>(sc.min_bin)); hk = vfma(eh[k], ah, splat<T>(sc.min_bin)); }
+    const auto ge = INV ? vge(v, py) : vge(v, px);
+    x0 = vsel(ge, px, x0); y0 = vsel(ge, py, y0);
+    bw = vsel(ge, wk, bw); bh = vsel(ge, hk, bh);
+    t0 = vsel(ge, th[2 * K + k], t0); t1 = vsel(ge, th[2 * K + k + 1], t1);
   }
-  const float d0 = knot_slope<FAST>(t0, sc), d1 = knot_slope<FAST>(t1, sc);
-  const float ibw = M::rcp(bw), ibh = M::rcp(bh);
-  const float s = bh * ibw;
-  const float st = d1 + d0 - 2.0f * s;
-  const float l2s = 2.0f * M::log(s);
-  rqs_bin_eval<INV, FAST>(v, x0, y0, bw, bh, ibw, ibh, s, st, d0, d1, l2s, out, ld);
-  if (v <= sc.lo) {          // bin 0 was selected: d0 = slope[0]
-    out = INV ? M::div(v - sc.lo, d0) + sc.lo : fmaf(v - sc.lo, d0, sc.lo);
-    ld = INV ? -M::log(d0) : M::log(d0);
-  }
-  if (v >= sc.hi) {          // bin K-1 was selected: d1 = slope[K]
-    out = INV ? M::div(v - sc.hi, d1) + sc.hi : fmaf(v - sc.hi, d1, sc.hi);
-    ld = INV ? -M::log(d1) : M::log(d1);
+  const T d0 = knot_slope<FAST, T>(t0, sc), d1 = knot_slope<FAST, T>(t1, sc);
+  const T ibw = M::rcp(bw), ibh = M::rcp(bh);
+  const T s = bh * ibw;
+  const T st = d1 + d0 - s * 2.0f;
+  const T l2s = M::log(s) * 2.0f;
+  rqs_bin_eval<INV, FAST, T>(v, x0, y0, bw, bh, ibw, ibh, s, st, d0, d1, l2s, out, ld);
+  const auto below = vle(v, sc.lo);          // bin 0 was selected: d0 = slope[0]
+  const auto above = vge(v, sc.hi);          // bin K-1 was selected: d1 = slope[K]
+  if (vany(below) || vany(above)) {
+    const T lo_out = INV ? M::div(v - sc.lo, d0) + sc.lo : vfma(v - sc.lo, d0, splat<T>(sc.lo));
+    const T hi_out = INV ? M::div(v - sc.hi, d1) + sc.hi : vfma(v - sc.hi, d1, splat<T>(sc.hi));
+    const T ld0 = M::log(d0), ld1 = M::log(d1);
+    out = vsel(below, lo_out, out);
+    ld = vsel(below, INV ? -ld0 : ld0, ld);
+    out = vsel(above, hi_out, out);
+    ld = vsel(above, INV ? -ld1 : ld1, ld);
   }
 }
 
 // ---------------------------------------------------------------------------
 // Conditioner MLP (flows.py:57-84): [c, v_0..v_{d-1}] -> H (relu) -> ... ->
-// H (relu) -> P.  One sample per lane; `w` is a wave-uniform pointer into the
-// prepared weights, so every weight is a scalar (SGPR) operand of the
-// per-lane FMA: no LDS or VGPR traffic for weights at all.  The d inputs v_q
-// are read from this thread's own LDS column `col[q * stride]`.
+// H (relu) -> P.  `w` is a wave-uniform pointer into the prepared weights, so
+// every weight is a scalar (SGPR) operand of the per-lane (packed) FMA: no LDS
+// or VGPR traffic for weights at all.  The d inputs v_q are read from this
+// thread's own LDS column.
 // ---------------------------------------------------------------------------
+
+// Pins every element in a VGPR at this point of the program: without it the
+// compiler sinks whole accumulation chains (and the 16x16 weights they need,
+// as spilled SGPRs) down to their first use in the spline code.
+template <int N> __device__ __forceinline__ void materialize(float (&v)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) asm volatile("" : "+v"(v[j]));
+}
+template <int N> __device__ __forceinline__ void materialize(v2f (&v)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) asm volatile("" : "+v"(v[j]));
+}
+
+template <int N> __device__ __forceinline__ void load_row(uniform_ptr p, float (&v)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) v[j] = p[j];
+}
+
 // acc[j] += sum_i in[i] * W[i][j] for a wave-uniform row-major W[R][N].
 // The rows are consumed in groups of G: each group is G*N scalar loads
 // (s_load_dwordx16) followed by G*N per-lane FMAs with an SGPR operand.  The
-// scheduling barrier after every group stops hipcc from hoisting ALL of the
-// layer's scalar loads to the top, which needs ~600 SGPRs and spills them to
-// VGPR lanes (v_writelane/v_readlane: 940 extra VALU ops per conditioner in the
-// first build).  Scalar-load latency is hidden by the other waves of the SIMD.
-template <int R, int N, int G>
-__device__ __forceinline__ void dense_acc(uniform_ptr W, const float (&in)[R], float (&acc)[N]) {
+// scheduling barrier after every group stops hipcc from clustering ALL of the
+// layer's scalar loads at the top (~600 SGPRs -> spilled to VGPR lanes).
+// Scalar-load latency is hidden by the other waves of the SIMD.
+template <int R, int N, int G, class T>
+__device__ __forceinline__ void dense_acc(uniform_ptr W, const T (&in)[R], T (&acc)[N]) {
   static_assert(R % G == 0, "row group must divide the row count");
 #pragma unroll
   for (int g = 0; g < R / G; ++g) {
@@ -253,34 +357,31 @@ __device__ __forceinline__ void dense_acc(uniform_ptr W, const float (&in)[R], f
 #pragma unroll
     for (int r = 0; r < G; ++r) {
 #pragma unroll
-      for (int j = 0; j < N; ++j) acc[j] = fmaf(in[g * G + r], wv[r * N + j], acc[j]);
+      for (int j = 0; j < N; ++j) acc[j] = vfma(wv[r * N + j], in[g * G + r], acc[j]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// Pins every element in a VGPR at this point of the program: without it the
-// compiler sinks whole accumulation chains (and the 16x16 weights they need,
-// as spilled SGPRs) down to their first use in the spline code.
-template <int N>
-__device__ __forceinline__ void materialize(float (&v)[N]) {
-#pragma unroll
-  for (int j = 0; j < N; ++j) asm volatile("" : "+v"(v[j]));
-}
-
-template <int N>
-__device__ __forceinline__ void load_row(uniform_ptr p, float (&v)[N]) {
-#pragma unroll
-  for (int j = 0; j < N; ++j) v[j] = p[j];
-}
-
 constexpr int row_group(int R, int N) { return (R % 2 == 0 && N <= 16) ? 2 : 1; }
 
-template <int H, int P>
-__device__ __forceinline__ void conditioner(uniform_ptr w, int d, int M, float c,
-                                            const float* col, int first_idx, int idx_step,
-                                            int stride, float (&th)[P]) {
-  float h[H];
+// this thread's value(s) of input dimension `idx` in its LDS column
+template <class T> __device__ __forceinline__ T lds_get(const float* col, int idx, int stride);
+template <> __device__ __forceinline__ float lds_get<float>(const float* col, int idx, int stride) {
+  return col[idx * stride];
+}
+template <> __device__ __forceinline__ v2f lds_get<v2f>(const float* col, int idx, int stride) {
+  return *reinterpret_cast<const v2f*>(col + idx * stride);
+}
+__device__ __forceinline__ void lds_put(float* col, int idx, int stride, float v) { col[idx * stride] = v; }
+__device__ __forceinline__ void lds_put(float* col, int idx, int stride, v2f v) {
+  *reinterpret_cast<v2f*>(col + idx * stride) = v;
+}
+
+template <int H, int P, class T>
+__device__ __forceinline__ void conditioner(uniform_ptr w, int d, int M, T c, const float* col,
+                                            int first_idx, int idx_step, int stride, T (&th)[P]) {
+  T h[H];
   w = launder(w);
   uniform_ptr b0 = w + (1 + d) * H;
   {
@@ -288,34 +389,44 @@ __device__ __forceinline__ void conditioner(uniform_ptr w, int d, int M, float c
     load_row<H>(w, wc);
     load_row<H>(b0, bb);
 #pragma unroll
-    for (int j = 0; j < H; ++j) h[j] = fmaf(c, wc[j], bb[j]);
+    for (int j = 0; j < H; ++j) h[j] = vfma(wc[j], c, splat<T>(bb[j]));
     __builtin_amdgcn_sched_barrier(0);
   }
   for (int q = 0; q < d; ++q) {              // runtime loop: d is not a template arg
-    const float v = col[(first_idx + q * idx_step) * stride];
+    const T v = lds_get<T>(col, first_idx + q * idx_step, stride);
     float wr[H];
     load_row<H>(w + (1 + q) * H, wr);
 #pragma unroll
-    for (int j = 0; j < H; ++j) h[j] = fmaf(v, wr[j], h[j]);
+    for (int j = 0; j < H; ++j) h[j] = vfma(wr[j], v, h[j]);
   }
 #pragma unroll
-  for (int j = 0; j < H; ++j) h[j] = fmaxf(h[j], 0.0f);
+  for (int j = 0; j < H; ++j) h[j] = vrelu(h[j]);
   materialize<H>(h);
   w = b0 + H;
   for (int m = 1; m < M; ++m) {
-    float g[H];
+    T g[H];
     uniform_ptr b = w + H * H;
-    load_row<H>(b, g);
-    __builtin_amdgcn_sched_barrier(0);
-    dense_acc<H, H, row_group(H, H)>(w, h, g);
+    {
+      float bb[H];
+      load_row<H>(b, bb);
 #pragma unroll
-    for (int j = 0; j < H; ++j) h[j] = fmaxf(g[j], 0.0f);
+      for (int j = 0; j < H; ++j) g[j] = splat<T>(bb[j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    dense_acc<H, H, row_group(H, H), T>(w, h, g);
+#pragma unroll
+    for (int j = 0; j < H; ++j) h[j] = vrelu(g[j]);
     materialize<H>(h);
     w = b + H;
   }
-  load_row<P>(w + H * P, th);
+  {
+    float bb[P];
+    load_row<P>(w + H * P, bb);
+#pragma unroll
+    for (int j = 0; j < P; ++j) th[j] = splat<T>(bb[j]);
+  }
   __builtin_amdgcn_sched_barrier(0);
-  dense_acc<H, P, row_group(H, P)>(w, h, th);
+  dense_acc<H, P, row_group(H, P), T>(w, h, th);
   materialize<P>(th);
 }
 

@@ -82,53 +82,58 @@ __global__ void prepare_kernel(const float* __restrict__ params, float* __restri
     const double v = (double)params[2 * K + k] + offset;
     dl[k] = fmax(v, 0.0) + log1p(exp(-fabs(v))) + min_slope;
   }
+  for (int i = 0; i < hdr; ++i) prep[i] = 0.0f;
   for (int k = 0; k < K; ++k) {
-    float* r = prep + k * ROW;
     const double bw = xk[k + 1] - xk[k], bh = yk[k + 1] - yk[k], s = bh / bw;
-    r[R_X0] = (float)xk[k];  r[R_Y0] = (float)yk[k];
-    r[R_BW] = (float)bw;     r[R_BH] = (float)bh;
-    r[R_IBW] = (float)(1.0 / bw); r[R_IBH] = (float)(1.0 / bh);
-    r[R_S] = (float)s;       r[R_ST] = (float)(dl[k + 1] + dl[k] - 2.0 * s);
-    r[R_D0] = (float)dl[k];  r[R_D1] = (float)dl[k + 1];
-    r[R_L2S] = (float)(2.0 * log(s)); r[R_PAD] = 0.0f;
+    prep[tab_off(F_X0, K) + k] = (float)xk[k];
+    prep[tab_off(F_Y0, K) + k] = (float)yk[k];
+    prep[tab_off(F_BW, K) + k] = (float)bw;
+    prep[tab_off(F_BH, K) + k] = (float)bh;
+    prep[tab_off(F_IBW, K) + k] = (float)(1.0 / bw);
+    prep[tab_off(F_IBH, K) + k] = (float)(1.0 / bh);
+    prep[tab_off(F_S, K) + k] = (float)s;
+    prep[tab_off(F_ST, K) + k] = (float)(dl[k + 1] + dl[k] - 2.0 * s);
+    prep[tab_off(F_D0, K) + k] = (float)dl[k];
+    prep[tab_off(F_D1, K) + k] = (float)dl[k + 1];
+    prep[tab_off(F_L2S, K) + k] = (float)(2.0 * log(s));
   }
   for (int k = 0; k <= K; ++k) {
-    prep[knot_x_off(K) + k] = (float)xk[k];
-    prep[knot_y_off(K) + k] = (float)yk[k];
+    prep[tab_off(F_XK, K) + k] = (float)xk[k];
+    prep[tab_off(F_YK, K) + k] = (float)yk[k];
   }
-  float* tl = prep + tail_off(K);
+  float* tl = prep + tab_off(F_TAIL, K);
   tl[T_DLO] = (float)dl[0];             tl[T_DHI] = (float)dl[K];
   tl[T_LOG_DLO] = (float)log(dl[0]);    tl[T_LOG_DHI] = (float)log(dl[K]);
   tl[T_INV_DLO] = (float)(1.0 / dl[0]); tl[T_INV_DHI] = (float)(1.0 / dl[K]);
-  for (int i = tail_off(K) + 6; i < hdr; ++i) prep[i] = 0.0f;
 }
 
 // ---------------------------------------------------------------------------
-// LDS tile: [hdr table][U: D x STRIDE][O: D x STRIDE]
+// LDS tile: [hdr table][U: D x TS][O: D x TS], TS = 256 * SPL samples per
+// workgroup.  Lane t owns samples SPL*t .. SPL*t+SPL-1 of the tile: its column
+// is U[d*TS + SPL*t] (one ds_read_b32 / ds_read_b64 per dimension,
+// conflict-free).
 // ---------------------------------------------------------------------------
-constexpr int STRIDE = TILE;   // per-thread columns: lane-consecutive, conflict-free
-
-__device__ __forceinline__ void tile_load(const float* __restrict__ g, float* U, int D,
+__device__ __forceinline__ void tile_load(const float* __restrict__ g, float* U, int D, int TS,
                                           int64_t tile_start, int64_t B) {
   const int64_t base = tile_start * D;
-  const int64_t n_el = (B - tile_start < TILE ? B - tile_start : TILE) * (int64_t)D;
-  for (int e = threadIdx.x; e < TILE * D; e += TILE) {
+  const int64_t n_el = (B - tile_start < TS ? B - tile_start : TS) * (int64_t)D;
+  for (int e = threadIdx.x; e < TS * D; e += TILE) {
     const int s = e / D, d = e - s * D;
-    U[d * STRIDE + s] = e < n_el ? g[base + e] : 0.0f;
+    U[d * TS + s] = e < n_el ? g[base + e] : 0.0f;
   }
 }
 
-__device__ __forceinline__ void tile_store(float* __restrict__ g, const float* U, int D,
+__device__ __forceinline__ void tile_store(float* __restrict__ g, const float* U, int D, int TS,
                                            int64_t tile_start, int64_t B) {
   const int64_t base = tile_start * D;
-  const int64_t n_el = (B - tile_start < TILE ? B - tile_start : TILE) * (int64_t)D;
-  for (int e = threadIdx.x; e < TILE * D; e += TILE) {
+  const int64_t n_el = (B - tile_start < TS ? B - tile_start : TS) * (int64_t)D;
+  for (int e = threadIdx.x; e < TS * D; e += TILE) {
     const int s = e / D, d = e - s * D;
-    if (e < n_el) g[base + e] = U[d * STRIDE + s];
+    if (e < n_el) g[base + e] = U[d * TS + s];
   }
 }
 
-__device__ __forceinline__ float load_cond(const FlowArgs& a, int64_t tile_start, int64_t i) {
+__device__ __forceinline__ float load_cond1(const FlowArgs& a, int64_t tile_start, int64_t i) {
   switch (a.c_mode) {
     case C_SINGLE: return a.c[0];
     case C_PER_SAMPLE: return i < a.B ? a.c[i] : 0.0f;
@@ -136,38 +141,50 @@ __device__ __forceinline__ float load_cond(const FlowArgs& a, int64_t tile_start
     default: return i < a.B ? a.c[i / a.c_block] : 0.0f;
   }
 }
+template <class T> __device__ __forceinline__ T load_cond(const FlowArgs& a, int64_t tile_start, int64_t i);
+template <> __device__ __forceinline__ float load_cond<float>(const FlowArgs& a, int64_t ts, int64_t i) {
+  return load_cond1(a, ts, i);
+}
+template <> __device__ __forceinline__ v2f load_cond<v2f>(const FlowArgs& a, int64_t ts, int64_t i) {
+  if (a.c_mode == C_SINGLE || a.c_mode == C_TILE_UNIFORM) return splat<v2f>(load_cond1(a, ts, i));
+  return v2f{load_cond1(a, ts, i), load_cond1(a, ts, i + 1)};
+}
 
-// One pass of the whole flow over the thread's own sample, in place in LDS.
+__device__ __forceinline__ float hsum(float v) { return v; }
+__device__ __forceinline__ v2f hsum(v2f v) { return v; }
+
+// One pass of the whole flow over the thread's own sample(s), in place in LDS.
 // TO_BASE=false: base -> data (chain.inverse, spline inverse, conditions on the
 // layer input: conditional.py:169-177, autoregressive.py:109-136).
 // TO_BASE=true : data -> base (chain.forward, spline forward, conditions on
 // already-produced outputs: conditional.py:159-167, autoregressive.py:76-107).
 // Returns the accumulated log|det J|; the result is left in `U` (swapped).
-template <int H, int K, bool TO_BASE, bool FAST>
-__device__ __forceinline__ float flow_pass(const FlowArgs& a, const float* tab, float*& U,
-                                           float*& O, float c) {
+template <int H, int K, bool TO_BASE, bool FAST, class T>
+__device__ __forceinline__ T flow_pass(const FlowArgs& a, const float* tab, float*& U, float*& O, T c) {
   constexpr int P = 3 * K + 1;
   constexpr bool INV = !TO_BASE;
+  constexpr int SPL = Lanes<T>::N;
+  constexpr int TS = TILE * SPL;
   uniform_ptr weights = as_uniform(a.prep + hdr_floats(K));
   const int D = a.D;
-  float acc = 0.0f;
+  T acc = splat<T>(0.0f);
   for (int step = 0; step < a.L; ++step) {
     const int l = TO_BASE ? a.L - 1 - step : step;
     const bool odd = l & 1;                       // flows.py:141-143 perms
     const int first_idx = odd ? D - 1 : 0, idx_step = odd ? -1 : 1;
-    float* cu = U + threadIdx.x;
-    float* co = O + threadIdx.x;
-    float o, ld;
-    table_spline<K, INV, FAST>(tab, cu[first_idx * STRIDE], a.sc, o, ld);
-    co[first_idx * STRIDE] = o;
+    float* cu = U + SPL * threadIdx.x;
+    float* co = O + SPL * threadIdx.x;
+    T o, ld;
+    table_spline<K, INV, FAST, T>(tab, lds_get<T>(cu, first_idx, TS), a.sc, o, ld);
+    lds_put(co, first_idx, TS, o);
     acc += ld;
     uniform_ptr w = weights + l * a.per_layer;
     for (int d = 1; d < D; ++d) {
       const int i = first_idx + d * idx_step;
-      float th[P];
-      conditioner<H, P>(w, d, a.M, c, TO_BASE ? co : cu, first_idx, idx_step, STRIDE, th);
-      cond_spline<K, INV, FAST>(th, cu[i * STRIDE], a.sc, o, ld);
-      co[i * STRIDE] = o;
+      T th[P];
+      conditioner<H, P, T>(w, d, a.M, c, TO_BASE ? co : cu, first_idx, idx_step, TS, th);
+      cond_spline<K, INV, FAST, T>(th, lds_get<T>(cu, i, TS), a.sc, o, ld);
+      lds_put(co, i, TS, o);
       acc += ld;
       w += cond_floats(d, H, a.M, P);
     }
@@ -176,46 +193,55 @@ __device__ __forceinline__ float flow_pass(const FlowArgs& a, const float* tab, 
   return acc;
 }
 
-template <int H, int K, bool TO_BASE, bool FAST>
+template <class T>
+__device__ __forceinline__ T base_logprob(const float* col, int D, int TS) {
+  T b = splat<T>(0.0f);
+  for (int d = 0; d < D; ++d) { const T x = lds_get<T>(col, d, TS); b = vfma(x * -0.5f, x, b); }
+  return b - D * HALF_LOG_2PI;
+}
+
+__device__ __forceinline__ void store_aux(float* aux, int64_t i, int64_t B, float r) {
+  if (i < B) aux[i] = r;
+}
+__device__ __forceinline__ void store_aux(float* aux, int64_t i, int64_t B, v2f r) {
+  if (i + 1 < B && ((reinterpret_cast<uintptr_t>(aux + i) & 7) == 0)) *reinterpret_cast<v2f*>(aux + i) = r;
+  else { if (i < B) aux[i] = r.x; if (i + 1 < B) aux[i + 1] = r.y; }
+}
+
+template <int H, int K, bool TO_BASE, bool FAST, class T>
 __global__ __launch_bounds__(TILE) void flow_kernel(const FlowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HDR = hdr_floats(K);
+  constexpr int SPL = Lanes<T>::N;
+  constexpr int TS = TILE * SPL;
   float* tab = lds;
   float* U = lds + HDR;
-  float* O = U + a.D * STRIDE;
+  float* O = U + a.D * TS;
   for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = a.prep[i];
 
-  const int64_t n_tiles = (a.B + TILE - 1) / TILE;
+  const int64_t n_tiles = (a.B + TS - 1) / TS;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t tile_start = tile * TILE;
-    const int64_t i = tile_start + threadIdx.x;
+    const int64_t tile_start = tile * TS;
+    const int64_t i = tile_start + SPL * threadIdx.x;
     __syncthreads();                       // previous tile's stores are done with U/O
-    tile_load(a.in, U, a.D, tile_start, a.B);
-    const float c = load_cond(a, tile_start, i);
+    tile_load(a.in, U, a.D, TS, tile_start, a.B);
+    const T c = load_cond<T>(a, tile_start, i);
     __syncthreads();
 
-    float base = 0.0f;
-    if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) {
-      for (int d = 0; d < a.D; ++d) { const float x = U[d * STRIDE + threadIdx.x]; base = fmaf(-0.5f * x, x, base); }
-      base -= a.D * HALF_LOG_2PI;
-    }
-    const float acc = flow_pass<H, K, TO_BASE, FAST>(a, tab, U, O, c);
-    if (a.aux && i < a.B) {
-      float r = acc;
+    T base = splat<T>(0.0f);
+    if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = base_logprob<T>(U + SPL * threadIdx.x, a.D, TS);
+    const T acc = flow_pass<H, K, TO_BASE, FAST, T>(a, tab, U, O, c);
+    if (a.aux) {
+      T r = acc;
       if (a.aux_mode == AUX_LOGPROB) {
-        if (TO_BASE) {   // log_prob = base(x) + ildj (conditional.py:316-321)
-          float b = 0.0f;
-          for (int d = 0; d < a.D; ++d) { const float x = U[d * STRIDE + threadIdx.x]; b = fmaf(-0.5f * x, x, b); }
-          r = b - a.D * HALF_LOG_2PI + acc;
-        } else {         // lp_y = lp_x - fldj (conditional.py:399-401)
-          r = base - acc;
-        }
+        // log_prob = base(x) + ildj (conditional.py:316-321); lp_y = lp_x - fldj (:399-401)
+        r = TO_BASE ? base_logprob<T>(U + SPL * threadIdx.x, a.D, TS) + acc : base - acc;
       }
-      a.aux[i] = r;
+      store_aux(a.aux, i, a.B, r);
     }
     if (a.out) {
       __syncthreads();
-      tile_store(a.out, U, a.D, tile_start, a.B);
+      tile_store(a.out, U, a.D, TS, tile_start, a.B);
     }
   }
 }
@@ -273,6 +299,7 @@ struct CnfModel {
   int device;
   int num_cus;
   int fast_math;          // 1: hardware transcendentals (default), 0: ocml
+  int force_spl;          // 0: automatic; 1 / 2: samples per lane (tests, bench)
   int params_set;
 };
 
@@ -280,10 +307,7 @@ struct CnfModel {
 #define CNF_KERNEL_CONFIGS(X) X(16, 5)
 #else
 #define CNF_KERNEL_CONFIGS(X) \
-  X(8, 4) X(8, 5) X(8, 8)     \
-  X(16, 4) X(16, 5) X(16, 8) X(16, 10) \
-  X(32, 5) X(32, 8) X(32, 10) \
-  X(64, 5) X(64, 8)
+  X(8, 5) X(16, 4) X(16, 5) X(16, 8) X(16, 10) X(32, 5) X(32, 8) X(64, 5)
 #endif
 
 static int config_valid(const CnfConfig* c) {
@@ -376,6 +400,13 @@ extern "C" int cnf_model_set_fast_math(CnfModel* m, int on) {
   return CNF_OK;
 }
 
+/* Internal knob: 0 = choose by batch size, 1 / 2 = force samples per lane. */
+extern "C" int cnf_model_set_samples_per_lane(CnfModel* m, int spl) {
+  if (!m || spl < 0 || spl > 2) return CNF_ERR_INVALID;
+  m->force_spl = spl;
+  return CNF_OK;
+}
+
 extern "C" int cnf_model_set_params(CnfModel* m, const float* params, void* stream) {
   if (!m || !params) return CNF_ERR_INVALID;
   const int K = m->cfg.num_bins;
@@ -391,19 +422,29 @@ extern "C" int cnf_model_set_params(CnfModel* m, const float* params, void* stre
   return CNF_OK;
 }
 
+// Two samples per lane (packed fp32) once the batch fills every SIMD with at
+// least one wave of sample pairs; one sample per lane below that.
+static int samples_per_lane(const CnfModel* m, int64_t B) {
+  if (m->force_spl == 1 || m->force_spl == 2) return m->force_spl;
+  return (m->fast_math && B >= (int64_t)m->num_cus * 4 * 64 * 2) ? 2 : 1;
+}
+
 template <bool TO_BASE>
-static int launch_flow(CnfModel* m, const FlowArgs& a, hipStream_t stream) {
-  const int64_t n_tiles = (a.B + TILE - 1) / TILE;
+static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stream) {
+  const int64_t ts = (int64_t)TILE * spl;
+  const int64_t n_tiles = (a.B + ts - 1) / ts;
   int64_t grid = n_tiles;
   const int64_t cap = (int64_t)m->num_cus * 8;
   if (grid > cap) grid = cap;
-  const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.D * STRIDE) * sizeof(float);
+  const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.D * ts) * sizeof(float);
 #define X(HH, KK)                                                                             \
   if (m->cfg.hidden_size == HH && m->cfg.num_bins == KK) {                                    \
-    if (m->fast_math)                                                                         \
-      hipLaunchKernelGGL((flow_kernel<HH, KK, TO_BASE, true>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);  \
+    if (!m->fast_math)                                                                        \
+      hipLaunchKernelGGL((flow_kernel<HH, KK, TO_BASE, false, float>), dim3((unsigned)grid), dim3(TILE), lds, stream, a); \
+    else if (spl == 2)                                                                        \
+      hipLaunchKernelGGL((flow_kernel<HH, KK, TO_BASE, true, v2f>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);    \
     else                                                                                      \
-      hipLaunchKernelGGL((flow_kernel<HH, KK, TO_BASE, false>), dim3((unsigned)grid), dim3(TILE), lds, stream, a); \
+      hipLaunchKernelGGL((flow_kernel<HH, KK, TO_BASE, true, float>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);  \
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;                            \
   }
   CNF_KERNEL_CONFIGS(X)
@@ -422,11 +463,13 @@ static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, 
   a.B = B; a.c_block = c_block; a.per_layer = m->per_layer;
   a.D = m->cfg.dim; a.L = m->cfg.num_layers; a.M = m->cfg.mlp_num_layers;
   a.aux_mode = aux_mode; a.sc = m->sc;
+  const int spl = m->fast_math ? samples_per_lane(m, B) : 1;
   if (c_block >= B) a.c_mode = C_SINGLE;
   else if (c_block == 1) a.c_mode = C_PER_SAMPLE;
-  else if (c_block % TILE == 0) a.c_mode = C_TILE_UNIFORM;
+  else if (c_block % (TILE * spl) == 0) a.c_mode = C_TILE_UNIFORM;
   else a.c_mode = C_GENERIC;
-  return to_base ? launch_flow<true>(m, a, (hipStream_t)stream) : launch_flow<false>(m, a, (hipStream_t)stream);
+  return to_base ? launch_flow<true>(m, a, spl, (hipStream_t)stream)
+                 : launch_flow<false>(m, a, spl, (hipStream_t)stream);
 }
 
 extern "C" int cnf_forward_logdet(CnfModel* m, const float* x, const float* c, int64_t c_block,

@@ -94,6 +94,11 @@ class FlowEngine:
   def set_fast_math(self, on: bool) -> None:
     _capi.check(self.lib.cnf_model_set_fast_math(self._h, 1 if on else 0), "cnf_model_set_fast_math")
 
+  def set_samples_per_lane(self, spl: int) -> None:
+    """0: chosen by batch size (default); 1 / 2: force the one-sample or the
+    packed two-samples-per-lane kernel."""
+    _capi.check(self.lib.cnf_model_set_samples_per_lane(self._h, int(spl)), "cnf_model_set_samples_per_lane")
+
   # -- helpers ---------------------------------------------------------------
   def _points(self, t, what) -> torch.Tensor:
     if not torch.is_tensor(t):

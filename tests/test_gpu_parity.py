@@ -70,13 +70,17 @@ GOLDEN = {
 }
 
 
-@pytest.mark.parametrize("fast", [True, False], ids=["fastmath", "ocml"])
+@pytest.mark.parametrize("variant", ["packed2", "fast1", "ocml1"])
 @pytest.mark.parametrize("name", sorted(GOLDEN))
-def test_golden_vectors(golden_dir, dev, name, fast):
+def test_golden_vectors(golden_dir, dev, name, variant):
+  """Every kernel variant: two samples per lane with packed fp32 math (the
+  large-batch default), one sample per lane, and one sample per lane with ocml
+  expf/logf + IEEE division instead of the hardware transcendentals."""
   fcfg, _ = _cfg_pair(**GOLDEN[name])
   g = np.load(os.path.join(golden_dir, name))
   eng = _engine(fcfg, g["params"], dev)
-  eng.set_fast_math(fast)
+  eng.set_fast_math(variant != "ocml1")
+  eng.set_samples_per_lane(2 if variant == "packed2" else 1)
   x = _t(g["noise"], dev)
   for tag, c in (("u", g["c_uniform"]), ("p", g["c_per"])):
     ct = _t(c, dev)
@@ -100,9 +104,10 @@ def test_golden_vectors(golden_dir, dev, name, fast):
   assert _err(lpv, g["lp_value_u"]).max() <= TOL_LP_DATA_MAX
 
 
+@pytest.mark.parametrize("spl", [1, 2])
 @pytest.mark.parametrize("params_kind", ["zeros", "random"])
 @pytest.mark.parametrize("t", [0.0, 0.5, 1.0])
-def test_config2_batch_65536_vs_oracle(dev, params_kind, t):
+def test_config2_batch_65536_vs_oracle(dev, params_kind, t, spl):
   """BASELINE config 2 / SURVEY.md 8(d): D=2, B=65 536, base noise N(0,I), c
   uniform t in {0, .5, 1}; params (i) zeros (identity), (ii) N(0, 0.2^2) seed 42."""
   import oracle
@@ -112,10 +117,11 @@ def test_config2_batch_65536_vs_oracle(dev, params_kind, t):
   params = np.zeros(n) if params_kind == "zeros" else rng.normal(0, 0.2, n).astype(np.float32).astype(np.float64)
   noise = rng.normal(size=(65536, 2)).astype(np.float32)
   eng = _engine(fcfg, params, dev)
+  eng.set_samples_per_lane(spl)
   y, lp = eng.sample_logprob(_t(noise, dev), torch.tensor([t], device=dev))
   y_ref, lp_ref = oracle.sample_logprob(ocfg, params, noise.astype(np.float64), [t])
   ey, elp = _err(y, y_ref), _err(lp, lp_ref)
-  print(f"\n[cfg2 {params_kind} t={t}] max|dy|={ey.max():.2e} max|dlogp|={elp.max():.2e} "
+  print(f"\n[cfg2 {params_kind} t={t} spl={spl}] max|dy|={ey.max():.2e} max|dlogp|={elp.max():.2e} "
         f"p99.9={np.quantile(elp, 0.999):.2e} median={np.median(elp):.2e}")
   assert ey.max() <= TOL_Y
   assert elp.max() <= TOL_LP_SAMPLE
@@ -137,6 +143,7 @@ def test_dim10_batch_vs_oracle(dev):
   params = rng.normal(0, 0.12, oracle.param_count(ocfg)).astype(np.float32).astype(np.float64)
   noise = rng.normal(size=(32768, 10)).astype(np.float32)
   eng = _engine(fcfg, params, dev)
+  eng.set_samples_per_lane(2)
   y, lp = eng.sample_logprob(_t(noise, dev), torch.tensor([0.3], device=dev))
   y_ref, lp_ref = oracle.sample_logprob(ocfg, params, noise.astype(np.float64), [0.3])
   print(f"\n[d10] max|dy|={_err(y, y_ref).max():.2e} max|dlogp|={_err(lp, lp_ref).max():.2e}")
@@ -187,7 +194,13 @@ def test_condition_layouts_agree(dev):
   from cnf_ot_amd import FlowConfig, FlowEngine, Params
   cfg = FlowConfig(dim=2)
   eng = FlowEngine(cfg, dev).load(Params.random(cfg, 0.2, seed=3, device=dev))
-  S, Bs = 6, 768                       # 6 slices of 768 (multiple of the 256 tile)
+  for spl in (1, 2):
+    eng.set_samples_per_lane(spl)
+    _check_condition_layouts(eng, dev)
+
+
+def _check_condition_layouts(eng, dev):
+  S, Bs = 6, 768                       # 6 slices of 768 (multiple of the 256 / not of the 512 tile)
   x = eng.normal(5, S * Bs)
   ts = torch.linspace(0, 1, S, device=dev)
   y_sl, lp_sl = eng.sample_logprob(x, ts)                              # c_block = 768
