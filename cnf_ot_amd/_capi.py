@@ -28,6 +28,18 @@ class CnfConfig(ctypes.Structure):
   ]
 
 
+class CnfLossSpec(ctypes.Structure):
+  _fields_ = [
+    ("kind", ctypes.c_int32), ("subtype", ctypes.c_int32),
+    ("dt", ctypes.c_float), ("dx", ctypes.c_float), ("coef", ctypes.c_float),
+    ("a", ctypes.c_float), ("T", ctypes.c_float), ("beta", ctypes.c_float),
+  ]
+
+
+TERM_KINETIC, TERM_KINETIC_SCORE, TERM_FLOW_MATCHING, TERM_POTENTIAL, TERM_REVERSE_KL, TERM_NEG_LOGPROB = range(6)
+POTENTIALS = {"quadratic": 0, "double_well": 1, "obstacle": 2}
+DRIFTS = {"ou": 0, "gradient": 1, "smile": 1, "nongradient": 2, "lorenz": 3}
+
 # name -> (restype, argtypes); every symbol include/cnf_ot_amd.h declares
 _P = ctypes.c_void_p
 _I64 = ctypes.c_int64
@@ -44,6 +56,7 @@ SYMBOLS = {
   "cnf_log_prob": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _P]),
   "cnf_sample_logprob": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
   "cnf_fill_normal": (ctypes.c_int, [_U64, _U64, _I64, _P, _P]),
+  "cnf_loss_terms": (ctypes.c_int, [_P, ctypes.POINTER(CnfLossSpec), _P, ctypes.c_int, _P, _I64, _I64, _P, _P]),
   "cnf_strerror": (ctypes.c_char_p, [ctypes.c_int]),
   "cnf_build_arch": (ctypes.c_char_p, []),
   "cnf_config_supported": (ctypes.c_int, [_CFG]),

@@ -30,18 +30,22 @@ constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
 enum CMode { C_SINGLE = 0, C_PER_SAMPLE = 1, C_TILE_UNIFORM = 2, C_GENERIC = 3 };
 enum AuxMode { AUX_LOGDET = 0, AUX_LOGPROB = 1 };
 
-struct FlowArgs {
+struct ModelArgs {
   const float* prep;     // prepared model buffer
+  int64_t per_layer;     // floats of conditioner weights per flow layer
+  int32_t D, L, M;
+  SplineConsts sc;
+};
+
+struct FlowArgs {
+  ModelArgs m;
   const float* in;       // [B, D]
   const float* c;        // conditions
   float* out;            // [B, D] or null
   float* aux;            // [B] logdet / logprob, or null
   int64_t B;
   int64_t c_block;
-  int64_t per_layer;     // floats of conditioner weights per flow layer
-  int32_t D, L, M;
   int32_t c_mode, aux_mode;
-  SplineConsts sc;
 };
 
 // ---------------------------------------------------------------------------
@@ -160,7 +164,7 @@ __device__ __forceinline__ v2f hsum(v2f v) { return v; }
 // already-produced outputs: conditional.py:159-167, autoregressive.py:76-107).
 // Returns the accumulated log|det J|; the result is left in `U` (swapped).
 template <int H, int K, bool TO_BASE, bool FAST, class T>
-__device__ __forceinline__ T flow_pass(const FlowArgs& a, const float* tab, float*& U, float*& O, T c) {
+__device__ __forceinline__ T flow_pass(const ModelArgs& a, const float* tab, float*& U, float*& O, T c) {
   constexpr int P = 3 * K + 1;
   constexpr bool INV = !TO_BASE;
   constexpr int SPL = Lanes<T>::N;
@@ -216,33 +220,201 @@ __global__ __launch_bounds__(TILE) void flow_kernel(const FlowArgs a) {
   constexpr int TS = TILE * SPL;
   float* tab = lds;
   float* U = lds + HDR;
-  float* O = U + a.D * TS;
-  for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = a.prep[i];
+  float* O = U + a.m.D * TS;
+  for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = a.m.prep[i];
 
   const int64_t n_tiles = (a.B + TS - 1) / TS;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t tile_start = tile * TS;
     const int64_t i = tile_start + SPL * threadIdx.x;
     __syncthreads();                       // previous tile's stores are done with U/O
-    tile_load(a.in, U, a.D, TS, tile_start, a.B);
+    tile_load(a.in, U, a.m.D, TS, tile_start, a.B);
     const T c = load_cond<T>(a, tile_start, i);
     __syncthreads();
 
     T base = splat<T>(0.0f);
-    if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = base_logprob<T>(U + SPL * threadIdx.x, a.D, TS);
-    const T acc = flow_pass<H, K, TO_BASE, FAST, T>(a, tab, U, O, c);
+    if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = base_logprob<T>(U + SPL * threadIdx.x, a.m.D, TS);
+    const T acc = flow_pass<H, K, TO_BASE, FAST, T>(a.m, tab, U, O, c);
     if (a.aux) {
       T r = acc;
       if (a.aux_mode == AUX_LOGPROB) {
         // log_prob = base(x) + ildj (conditional.py:316-321); lp_y = lp_x - fldj (:399-401)
-        r = TO_BASE ? base_logprob<T>(U + SPL * threadIdx.x, a.D, TS) + acc : base - acc;
+        r = TO_BASE ? base_logprob<T>(U + SPL * threadIdx.x, a.m.D, TS) + acc : base - acc;
       }
       store_aux(a.aux, i, a.B, r);
     }
     if (a.out) {
       __syncthreads();
-      tile_store(a.out, U, a.D, TS, tile_start, a.B);
+      tile_store(a.out, U, a.m.D, TS, tile_start, a.B);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// loss_kernel: fused Monte-Carlo loss terms (cnf_ot/mfc/applications.py
+// :129-374, cnf_ot/utils.py:311-389).  One tile of samples of one time-slice
+// per workgroup iteration; several flow passes share the tile's base noise in
+// LDS (the reference reuses one rng for them: applications.py:233-239); only
+// one double per tile leaves the chip (atomicAdd into sums[slice]).
+// LDS: [hdr][N noise][U][O][V velocity][R r3], each D x TS.
+// ---------------------------------------------------------------------------
+struct LossArgs {
+  ModelArgs m;
+  CnfLossSpec spec;
+  const float* pts;     // base noise (or data points for NEG_LOGPROB)
+  const float* t;       // [n_slices]
+  double* sums;         // [n_slices]
+  int64_t B;            // samples per slice
+  int64_t n_slices;
+  int64_t pts_slice_stride;   // samples between slices in pts (0: shared draw)
+};
+
+template <class T>
+__device__ __forceinline__ void copy_cols(float* dst, const float* src, int D, int TS) {
+  for (int d = 0; d < D; ++d) lds_put(dst, d, TS, lds_get<T>(src, d, TS));
+}
+
+// target drift of flow_matching_loss_fn at r (this thread's column `r3`), dim i
+template <class T>
+__device__ __forceinline__ T drift_of(const float* r3, int i, int D, int TS, int subtype, float a) {
+  const T ri = lds_get<T>(r3, i, TS);
+  switch (subtype) {
+    case CNF_DRIFT_SMILE: {          // applications.py:353-357 (2-D)
+      const T x = lds_get<T>(r3, 0, TS), y = lds_get<T>(r3, 1, TS);
+      const T q = x * x + y * y - 4.0f;
+      return (i == 0 ? -q * x : -q * y - (y - 1.0f) * 2.0f) * a;
+    }
+    case CNF_DRIFT_NONGRADIENT: {    // applications.py:358-363: -a r + 0.5 (r @ J), J=[[0,1],[-1,0]]
+      const T x = lds_get<T>(r3, 0, TS), y = lds_get<T>(r3, 1, TS);
+      return i == 0 ? x * -a - y * 0.5f : y * -a + x * 0.5f;
+    }
+    case CNF_DRIFT_LORENZ: {         // applications.py:364-372, _r = 9
+      const T x = lds_get<T>(r3, 0, TS), y = lds_get<T>(r3, 1, TS), z = lds_get<T>(r3, 2, TS);
+      if (i == 0) return (y - x) * 10.0f;
+      if (i == 1) return x * 9.0f * (splat<T>(28.0f / 9.0f) - z) - y;
+      return x * 9.0f * y - z * (8.0f / 3.0f);
+    }
+    default: return ri * -a;         // OU drift, applications.py:310
+  }
+}
+
+template <bool FAST, class T>
+__device__ __forceinline__ T potential_of(const float* y, int D, int TS, int subtype, float a) {
+  using M = Math<FAST>;
+  if (subtype == CNF_POT_DOUBLE_WELL) {      // (|r-a1| |r+a1| / 2)^2, applications.py:184-188
+    T sm = splat<T>(0.0f), sp = splat<T>(0.0f);
+    for (int d = 0; d < D; ++d) {
+      const T r = lds_get<T>(y, d, TS);
+      sm = vfma(r - a, r - a, sm);
+      sp = vfma(r + a, r + a, sp);
+    }
+    return sm * sp * 0.25f;
+  }
+  T s2 = splat<T>(0.0f);
+  for (int d = 0; d < D; ++d) { const T r = lds_get<T>(y, d, TS); s2 = vfma(r, r, s2); }
+  if (subtype == CNF_POT_OBSTACLE) return M::exp(s2 * -0.5f) * 50.0f;   // applications.py:190-191
+  return s2 * 0.5f;                                                      // quadratic, :181-182
+}
+
+__device__ __forceinline__ float mask_tail(float v, int64_t i, int64_t B) { return i < B ? v : 0.0f; }
+__device__ __forceinline__ float mask_tail(v2f v, int64_t i, int64_t B) {
+  return (i < B ? v.x : 0.0f) + (i + 1 < B ? v.y : 0.0f);
+}
+
+template <int H, int K, bool FAST, class T>
+__global__ __launch_bounds__(TILE) void loss_kernel(const LossArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int HDR = hdr_floats(K);
+  constexpr int SPL = Lanes<T>::N;
+  constexpr int TS = TILE * SPL;
+  using M = Math<FAST>;
+  const int D = a.m.D;
+  float* tab = lds;
+  float* Nn = lds + HDR;
+  float* U = Nn + D * TS;
+  float* O = U + D * TS;
+  float* V = O + D * TS;
+  float* R = V + D * TS;
+  for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = a.m.prep[i];
+  const int col = SPL * threadIdx.x;
+  const int kind = a.spec.kind;
+
+  const int64_t tiles_per_slice = (a.B + TS - 1) / TS;
+  const int64_t n_tiles = tiles_per_slice * a.n_slices;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t slice = tile / tiles_per_slice;
+    const int64_t tile_start = (tile - slice * tiles_per_slice) * TS;
+    const int64_t i = tile_start + col;
+    __syncthreads();
+    tile_load(a.pts + slice * a.pts_slice_stride * D, Nn, D, TS, tile_start, a.B);
+    const float t = a.t[slice];
+    __syncthreads();
+
+    // Each flow direction is instantiated ONCE (a pass is ~2.5k instructions;
+    // one inlined copy per use would overflow the 64 KB instruction cache):
+    // the base->data passes run in a loop over (condition, destination), the
+    // data->base passes in a loop over (dimension, sign).
+    T acc = splat<T>(0.0f);
+    const float dt = a.spec.dt;
+    const bool kin = kind <= CNF_TERM_FLOW_MATCHING;
+    const int n_fwd = kind == CNF_TERM_NEG_LOGPROB ? 0 : (kind == CNF_TERM_KINETIC ? 2 : (kin ? 3 : 1));
+    T fldj = splat<T>(0.0f);
+    for (int p = 0; p < n_fwd; ++p) {
+      const float c = !kin ? t : (p == 0 ? t - 0.5f * dt : (p == 1 ? t + 0.5f * dt : t));
+      copy_cols<T>(U + col, Nn + col, D, TS);
+      fldj = flow_pass<H, K, false, FAST, T>(a.m, tab, U, O, splat<T>(c));
+      if (kin) {
+        if (p == 0) copy_cols<T>(V + col, U + col, D, TS);                       // r1
+        else if (p == 1) {                                                      // velocity = (r2 - r1)/dt
+          const float inv_dt = 1.0f / dt;
+          for (int d = 0; d < D; ++d)
+            lds_put(V + col, d, TS, (lds_get<T>(U + col, d, TS) - lds_get<T>(V + col, d, TS)) * inv_dt);
+        } else copy_cols<T>(R + col, U + col, D, TS);                            // r3
+      }
+    }
+    if (kind == CNF_TERM_KINETIC) {
+      for (int d = 0; d < D; ++d) { const T v = lds_get<T>(V + col, d, TS); acc = vfma(v, v, acc); }
+    } else if (kind == CNF_TERM_POTENTIAL) {
+      acc = potential_of<FAST, T>(U + col, D, TS, a.spec.subtype, a.spec.a);
+    } else if (kind == CNF_TERM_REVERSE_KL) {
+      const T lp = base_logprob<T>(Nn + col, D, TS) - fldj;
+      T s2 = splat<T>(0.0f);
+      for (int d = 0; d < D; ++d) { const T r = lds_get<T>(U + col, d, TS); s2 = vfma(r, r, s2); }
+      // log(N(y;0,vs I) ws + N(y;0,vt I) wt) as a log-sum-exp (applications.py:136-163)
+      const float Tt = a.spec.T, vs = 2.0f / a.spec.beta * (Tt + 1.0f), vt = 2.0f / a.spec.beta;
+      const float ws = (Tt - t) / Tt, wt = t / Tt;
+      const float ls = -0.5f * D * logf(6.283185307179586f * vs), lt = -0.5f * D * logf(6.283185307179586f * vt);
+      const T as = vfma(s2, splat<T>(-0.5f / vs), splat<T>(ls));
+      const T at = vfma(s2, splat<T>(-0.5f / vt), splat<T>(lt));
+      const T mx = vmax(as, at);
+      const T mix = M::exp(as - mx) * ws + M::exp(at - mx) * wt;
+      acc = lp - (mx + M::log(mix));
+    }
+    // data->base passes: NEG_LOGPROB (one, on the points themselves) or the
+    // central differences of log_prob at r3 +- dx/2 e_d (applications.py:264-273)
+    const bool neg = kind == CNF_TERM_NEG_LOGPROB;
+    const int n_tb = neg ? 1 : ((kind == CNF_TERM_KINETIC_SCORE || kind == CNF_TERM_FLOW_MATCHING) ? 2 * D : 0);
+    const float dx = a.spec.dx;
+    T lp0 = splat<T>(0.0f);
+    for (int e = 0; e < n_tb; ++e) {
+      const int d = e >> 1, sgn = e & 1;
+      copy_cols<T>(U + col, (neg ? Nn : R) + col, D, TS);
+      if (!neg) lds_put(U + col, d, TS, lds_get<T>(R + col, d, TS) + (sgn == 0 ? 0.5f * dx : -0.5f * dx));
+      const T ildj = flow_pass<H, K, true, FAST, T>(a.m, tab, U, O, splat<T>(t));
+      const T lp = base_logprob<T>(U + col, D, TS) + ildj;
+      if (neg) acc = -lp;
+      else if (sgn == 0) lp0 = lp;
+      else {
+        T v = vfma((lp0 - lp) * (1.0f / dx), splat<T>(a.spec.coef), lds_get<T>(V + col, d, TS));
+        if (kind == CNF_TERM_FLOW_MATCHING) v -= drift_of<T>(R + col, d, D, TS, a.spec.subtype, a.spec.a);
+        acc = vfma(v, v, acc);
+      }
+    }
+    // tile reduction: lanes -> wave (shuffles) -> one double atomic per wave
+    float part = mask_tail(acc, i, a.B);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(a.sums + slice, (double)part);
   }
 }
 
@@ -422,6 +594,14 @@ extern "C" int cnf_model_set_params(CnfModel* m, const float* params, void* stre
   return CNF_OK;
 }
 
+static ModelArgs model_args(const CnfModel* m) {
+  ModelArgs a;
+  a.prep = m->prep; a.per_layer = m->per_layer;
+  a.D = m->cfg.dim; a.L = m->cfg.num_layers; a.M = m->cfg.mlp_num_layers;
+  a.sc = m->sc;
+  return a;
+}
+
 // Two samples per lane (packed fp32) once the batch fills every SIMD with at
 // least one wave of sample pairs; one sample per lane below that.
 static int samples_per_lane(const CnfModel* m, int64_t B) {
@@ -436,7 +616,7 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
   int64_t grid = n_tiles;
   const int64_t cap = (int64_t)m->num_cus * 8;
   if (grid > cap) grid = cap;
-  const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.D * ts) * sizeof(float);
+  const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * ts) * sizeof(float);
 #define X(HH, KK)                                                                             \
   if (m->cfg.hidden_size == HH && m->cfg.num_bins == KK) {                                    \
     if (!m->fast_math)                                                                        \
@@ -459,10 +639,10 @@ static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, 
   if (!m->params_set) return CNF_ERR_INVALID;
   if (B == 0) return CNF_OK;
   FlowArgs a;
-  a.prep = m->prep; a.in = in; a.c = c; a.out = out; a.aux = aux;
-  a.B = B; a.c_block = c_block; a.per_layer = m->per_layer;
-  a.D = m->cfg.dim; a.L = m->cfg.num_layers; a.M = m->cfg.mlp_num_layers;
-  a.aux_mode = aux_mode; a.sc = m->sc;
+  a.m = model_args(m);
+  a.in = in; a.c = c; a.out = out; a.aux = aux;
+  a.B = B; a.c_block = c_block;
+  a.aux_mode = aux_mode;
   const int spl = m->fast_math ? samples_per_lane(m, B) : 1;
   if (c_block >= B) a.c_mode = C_SINGLE;
   else if (c_block == 1) a.c_mode = C_PER_SAMPLE;
@@ -504,4 +684,56 @@ extern "C" int cnf_fill_normal(uint64_t seed, uint64_t first_element, int64_t n,
   hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, seed,
                      first_element, n, out);
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+
+extern "C" int cnf_loss_terms(CnfModel* m, const CnfLossSpec* spec, const float* pts, int pts_shared,
+                              const float* t, int64_t n_slices, int64_t B, double* sums, void* stream_) {
+  if (!m || !spec || !pts || !t || !sums || n_slices < 0 || B < 0) return CNF_ERR_INVALID;
+  if (!m->params_set) return CNF_ERR_INVALID;
+  if (spec->kind < CNF_TERM_KINETIC || spec->kind > CNF_TERM_NEG_LOGPROB) return CNF_ERR_INVALID;
+  const int D = m->cfg.dim;
+  if (spec->kind <= CNF_TERM_FLOW_MATCHING && !(spec->dt > 0.f)) return CNF_ERR_INVALID;
+  if ((spec->kind == CNF_TERM_KINETIC_SCORE || spec->kind == CNF_TERM_FLOW_MATCHING) && !(spec->dx > 0.f))
+    return CNF_ERR_INVALID;
+  if (spec->kind == CNF_TERM_FLOW_MATCHING) {
+    // the reference raises for these (applications.py:359,365); SMILE is 2-D by construction
+    if ((spec->subtype == CNF_DRIFT_SMILE || spec->subtype == CNF_DRIFT_NONGRADIENT) && D != 2) return CNF_ERR_INVALID;
+    if (spec->subtype == CNF_DRIFT_LORENZ && D != 3) return CNF_ERR_INVALID;
+    if (spec->subtype < CNF_DRIFT_OU || spec->subtype > CNF_DRIFT_LORENZ) return CNF_ERR_INVALID;
+  }
+  if (spec->kind == CNF_TERM_POTENTIAL && (spec->subtype < CNF_POT_QUADRATIC || spec->subtype > CNF_POT_OBSTACLE))
+    return CNF_ERR_INVALID;
+  if (spec->kind == CNF_TERM_REVERSE_KL && (!(spec->T > 0.f) || !(spec->beta > 0.f))) return CNF_ERR_INVALID;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_slices == 0) return CNF_OK;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * (size_t)n_slices, stream) != hipSuccess) return CNF_ERR_HIP;
+  if (B == 0) return CNF_OK;
+
+  LossArgs a;
+  a.m = model_args(m); a.spec = *spec; a.pts = pts; a.t = t; a.sums = sums;
+  a.B = B; a.n_slices = n_slices; a.pts_slice_stride = pts_shared ? 0 : B;
+  // five D x TS buffers: keep a workgroup under ~64 KB of LDS
+  int spl = (m->fast_math && n_slices * B >= (int64_t)m->num_cus * 4 * 64 * 2) ? 2 : 1;
+  if (m->force_spl == 1 || m->force_spl == 2) spl = m->fast_math ? m->force_spl : 1;
+  if (spl == 2 && (size_t)(5 * D * TILE * 2) * sizeof(float) > 96 * 1024) spl = 1;
+  const int64_t ts = (int64_t)TILE * spl;
+  const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 5 * D * ts) * sizeof(float);
+  if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
+  int64_t grid = ((B + ts - 1) / ts) * n_slices;
+  const int64_t cap = (int64_t)m->num_cus * 8;
+  if (grid > cap) grid = cap;
+#define X(HH, KK)                                                                             \
+  if (m->cfg.hidden_size == HH && m->cfg.num_bins == KK) {                                    \
+    if (!m->fast_math)                                                                        \
+      hipLaunchKernelGGL((loss_kernel<HH, KK, false, float>), dim3((unsigned)grid), dim3(TILE), lds, stream, a); \
+    else if (spl == 2)                                                                        \
+      hipLaunchKernelGGL((loss_kernel<HH, KK, true, v2f>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);    \
+    else                                                                                      \
+      hipLaunchKernelGGL((loss_kernel<HH, KK, true, float>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);  \
+    return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;                            \
+  }
+  CNF_KERNEL_CONFIGS(X)
+#undef X
+  return CNF_ERR_UNSUPPORTED;
 }

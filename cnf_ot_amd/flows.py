@@ -179,6 +179,26 @@ class FlowEngine:
     return self._run(self.lib.cnf_sample_logprob, "cnf_sample_logprob", noise, cond, True, want_logp,
                      out=out, aux=logp_out)
 
+  def loss_terms(self, spec: "_capi.CnfLossSpec", pts, t, B: int, shared: bool) -> torch.Tensor:
+    """cnf_loss_terms: per-slice SUMS (float64 [n_slices]) of one Monte-Carlo
+    loss term.  pts: base noise (or data points) [B, D] if `shared` else
+    [n_slices*B, D]; t: [n_slices]."""
+    pts = self._points(pts, "loss_terms")
+    if not torch.is_tensor(t):
+      t = torch.as_tensor(np.asarray(t, dtype=np.float32))
+    t = t.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+    n_slices = t.numel()
+    need = B if shared else n_slices * B
+    if pts.shape[0] != need:
+      raise ValueError(f"loss_terms: pts has {pts.shape[0]} rows, expected {need}")
+    sums = torch.empty(n_slices, dtype=torch.float64, device=self.device)
+    if n_slices > 0:
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_loss_terms(self._h, _capi.ctypes.byref(spec), pts.data_ptr(),
+                                            1 if shared else 0, t.data_ptr(), n_slices, B,
+                                            sums.data_ptr(), _stream_ptr(self.device)), "cnf_loss_terms")
+    return sums
+
   def normal(self, seed, n_samples: int, first_sample: int = 0) -> torch.Tensor:
     """Base noise [n_samples, D]: Philox stream element (first_sample+i)*D+d."""
     seed, off = seed_to_u64(seed)
@@ -286,6 +306,14 @@ class FlowModel:
     if eng is None:
       eng = self._engines[device] = FlowEngine(self.cfg, device)
     return eng
+
+  def terms_backend(self, params, device=None) -> FlowEngine:
+    """The engine that evaluates fused loss terms for `params` (used by
+    cnf_ot_amd.applications / cnf_ot_amd.utils)."""
+    if device is None:
+      device = params.flat.device if isinstance(params, Params) and params.flat.is_cuda else \
+        torch.device("cuda", torch.cuda.current_device())
+    return self.engine(device).load(params)
 
   def init(self, rng=0, x=None, c=None, device=None) -> Params:
     """model.init(rng, zeros((1,dim)), zeros((1,))) (solvers.py:54): identity

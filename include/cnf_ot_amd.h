@@ -125,6 +125,55 @@ int cnf_sample_logprob(CnfModel *m, const float *noise, const float *c,
 int cnf_fill_normal(uint64_t seed, uint64_t first_element, int64_t n,
                     float *out, void *stream);
 
+/* ---- fused Monte-Carlo loss terms (cnf_ot/mfc/applications.py) ------------
+ * One launch evaluates one term over n_slices time-slices x B samples and
+ * returns, per slice, the SUM over that slice's samples (double, device); the
+ * caller divides by the global sample count and composes the losses
+ * (applications.py:377-441), after an all-reduce when samples are sharded.
+ * No [B,D] intermediate reaches HBM. */
+enum CnfTermKind {
+  /* kinetic_loss_fn, applications.py:220-242 (and utils.py:311-340):
+   * sum_{i,d} ((F(x_i,t+dt/2) - F(x_i,t-dt/2)) / dt)^2 on the SAME base noise */
+  CNF_TERM_KINETIC = 0,
+  /* kinetic_with_score_loss_fn, applications.py:245-276 (utils.py:343-389):
+   * v = (r2-r1)/dt + coef * score(r3), score_d by central differences of
+   * log_prob at r3 +- dx/2 e_d; sum_{i,d} v^2; coef = 1/beta */
+  CNF_TERM_KINETIC_SCORE = 1,
+  /* flow_matching_loss_fn, applications.py:279-374: as above with coef = sigma
+   * and sum_{i,d} (v - drift_d(r3))^2; drift by `subtype` */
+  CNF_TERM_FLOW_MATCHING = 2,
+  /* potential_loss_fn, applications.py:176-205: sum_i V(F(x_i,t)) */
+  CNF_TERM_POTENTIAL = 3,
+  /* reverse_kl_loss_fn, applications.py:129-163:
+   * sum_i log_prob_i - log(N(y_i;0,2/beta (T+1) I)(T-t)/T + N(y_i;0,2/beta I) t/T) */
+  CNF_TERM_REVERSE_KL = 4,
+  /* kl_loss_fn, applications.py:11-86 (after the host mixed the samples):
+   * sum_i -log_prob(value_i; t); pts are DATA points, not base noise */
+  CNF_TERM_NEG_LOGPROB = 5
+};
+enum CnfPotential { CNF_POT_QUADRATIC = 0, CNF_POT_DOUBLE_WELL = 1, CNF_POT_OBSTACLE = 2 };
+/* drift of flow_matching_loss_fn: OU = -a r (applications.py:310, README);
+ * SMILE = the 2-D field that overwrites it (applications.py:353-357);
+ * NONGRADIENT (:358-363, dim 2); LORENZ (:364-372, dim 3) */
+enum CnfDrift { CNF_DRIFT_OU = 0, CNF_DRIFT_SMILE = 1, CNF_DRIFT_NONGRADIENT = 2, CNF_DRIFT_LORENZ = 3 };
+
+typedef struct CnfLossSpec {
+  int32_t kind;      /* CnfTermKind                                         */
+  int32_t subtype;   /* CnfPotential or CnfDrift                            */
+  float dt, dx;      /* finite-difference steps (general.dt / general.dx)   */
+  float coef;        /* 1/beta (KINETIC_SCORE) or sigma (FLOW_MATCHING)     */
+  float a;           /* potential / drift parameter (rwpo.a, fp.a)          */
+  float T, beta;     /* REVERSE_KL                                          */
+} CnfLossSpec;
+
+/* pts: [n_slices * B, D] when pts_shared == 0 (each slice its own draw, the
+ * key-split of utils.py:328), [B, D] when pts_shared != 0 (every slice reuses
+ * the same draw: the reused rng of applications.py:392-400).  t: [n_slices].
+ * sums: [n_slices] doubles, overwritten. */
+int cnf_loss_terms(CnfModel *m, const CnfLossSpec *spec, const float *pts,
+                   int pts_shared, const float *t, int64_t n_slices, int64_t B,
+                   double *sums, void *stream);
+
 const char *cnf_strerror(int code);
 /* "gfx950" etc.: the offload arch this library was compiled for. */
 const char *cnf_build_arch(void);
