@@ -52,15 +52,23 @@ def parse_args():
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-seconds", type=float, default=12.0)
   ap.add_argument("--no-per-call", action="store_true")
+  ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' + "
+                  "--share-device rehearses the multi-rank path on a one-GPU box")
+  ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+  ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline "
+                  "(0: min(16, affinity): a one-GPU box's CPU share)")
   return ap.parse_args()
 
 
-def cpu_baseline(params64, seconds):
+def cpu_baseline(params64, seconds, threads=0):
   """The oracle (float64 C restatement, OpenMP over the host cores) timed on a
   bounded sample of the same workload.  A reported baseline, not the target."""
   import oracle
   ocfg = oracle.OracleConfig(D=DIM)
   oracle.build_library()
+  if threads <= 0:
+    threads = min(16, len(os.sched_getaffinity(0)))
+  oracle.set_num_threads(threads)
   rng = np.random.default_rng(0)
   noise = rng.normal(size=(BATCH, DIM))
   oracle.sample_logprob(ocfg, params64, noise, [0.5])          # warm-up
@@ -89,12 +97,15 @@ def main():
       raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     args.gpus = world
   assert torch.cuda.is_available(), "bench.py needs an MI355X (ROCm) device"
-  dev = torch.device("cuda", local_rank)
+  dev = torch.device("cuda", 0 if args.share_device else local_rank)
   torch.cuda.set_device(dev)
   dist = None
   if world > 1:
     import torch.distributed as dist
-    dist.init_process_group("nccl", device_id=dev)
+    if args.backend == "nccl":
+      dist.init_process_group("nccl", device_id=dev)
+    else:
+      dist.init_process_group(args.backend)
 
   from cnf_ot_amd import FlowConfig, FlowEngine, Params
 
@@ -145,7 +156,7 @@ def main():
   elapsed = time.perf_counter() - t0
   if dist is not None:
     dist.barrier()
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
   assert torch.isfinite(lp).all(), "non-finite log_prob in the bench output"
@@ -201,7 +212,7 @@ def main():
                         "note": "one launch per 65536-sample step, eager, same kernel"}
 
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
-    line["cpu_baseline"] = cpu_baseline(params.flat.cpu().double().numpy(), args.cpu_seconds)
+    line["cpu_baseline"] = cpu_baseline(params.flat.cpu().double().numpy(), args.cpu_seconds, args.cpu_threads)
   elif rank == 0:
     line["cpu_baseline"] = None
 

@@ -363,7 +363,7 @@ __device__ __forceinline__ void dense_acc(uniform_ptr W, const T (&in)[R], T (&a
   }
 }
 
-constexpr int row_group(int R, int N) { return (R % 2 == 0 && N <= 16) ? 2 : 1; }
+constexpr int row_group(int R, int N) { return 1; }
 
 // this thread's value(s) of input dimension `idx` in its LDS column
 template <class T> __device__ __forceinline__ T lds_get(const float* col, int idx, int stride);
@@ -429,6 +429,123 @@ __device__ __forceinline__ void conditioner(uniform_ptr w, int d, int M, T c, co
   dense_acc<H, P, row_group(H, P), T>(w, h, th);
   materialize<P>(th);
 }
+
+// ---------------------------------------------------------------------------
+// MFMA conditioner (H = 16, P = 16 only: the reference's network).  The two
+// 16x16 matmuls of the MLP run on the matrix cores as exact-fp32
+// v_mfma_f32_16x16x4_f32, freeing ~80 % of the conditioner's VALU slots for the
+// spline code of the other waves (VALU and MFMA pipes issue concurrently).
+//
+// Layouts (lane l: g = l >> 4, s = l & 15):
+//   * sample groups: group q is the 16 samples owned by lanes 16*(q / N) + s,
+//     component q % N (N = samples per lane): Q = 4*N groups per wave;
+//   * D = W^T * H^T per group: samples on the N axis.  MFMA operand maps
+//     (checked on hardware by scripts/probes/mfma_probe.hip): A lane (g,i) holds
+//     A[i][k=g], B lane (g,s) holds B[k=g][n=s], result lane (g,s) register r
+//     holds D[row=4g+r][col=s];
+//   * the k index of step t is permuted to k = 4g + t, so that a layer's
+//     result registers ARE the next layer's B operands (register r = step t):
+//     chained layers need no lane movement at all.  A-operands and biases are
+//     pre-permuted accordingly by prepare_kernel (`wq`, one float4 per lane
+//     per field: W0 rows, b0, then {A, bias} per dense layer);
+//   * entry: the first layer (K = 1+d inputs) is evaluated directly in the B
+//     layout; a lane fetches c and v of the group's sample with ds_bpermute;
+//   * exit: the 16 spline parameters of a sample sit in 4 lanes x 4 registers;
+//     a 4x4 transpose over lane blocks (2 x v_permlane32_swap +
+//     2 x v_permlane16_swap per register quad) brings them to the sample's lane.
+// ---------------------------------------------------------------------------
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float comp_of(float v, int) { return v; }
+__device__ __forceinline__ float comp_of(v2f v, int i) { return i == 0 ? v.x : v.y; }
+
+__device__ __forceinline__ float lane_fetch(int byte_addr, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+
+// in-place 4x4 transpose between register index b and lane block g
+__device__ __forceinline__ void transpose4(float& x0, float& x1, float& x2, float& x3) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x0), __float_as_uint(x2), false, false);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x1), __float_as_uint(x3), false, false);
+  auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+  auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+  x0 = __uint_as_float(c[0]); x1 = __uint_as_float(c[1]);
+  x2 = __uint_as_float(d[0]); x3 = __uint_as_float(d[1]);
+}
+
+__device__ __forceinline__ void set_comp(float& dst, int, float v) { dst = v; }
+__device__ __forceinline__ void set_comp(v2f& dst, int i, float v) { if (i == 0) dst.x = v; else dst.y = v; }
+
+template <class T>
+__device__ __forceinline__ void conditioner_mfma(const f4* __restrict__ wq, int d, int M, T c,
+                                                 const float* col, int first_idx, int idx_step,
+                                                 int stride, T (&th)[16]) {
+  constexpr int N = Lanes<T>::N;
+  constexpr int Q = 4 * N;
+  const int lane = threadIdx.x & 63;
+  const int s15 = lane & 15;
+  float h[Q][4];
+  {
+    const f4 w0c = wq[lane];
+    const f4 b0 = wq[(1 + d) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const float cq = lane_fetch(4 * (16 * (q / N) + s15), comp_of(c, q % N));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h[q][t] = fmaf(w0c[t], cq, b0[t]);
+    }
+  }
+  for (int row = 0; row < d; ++row) {          // runtime loop over the d conditioning inputs
+    const T v = lds_get<T>(col, first_idx + row * idx_step, stride);
+    const f4 w = wq[(1 + row) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const float vq = lane_fetch(4 * (16 * (q / N) + s15), comp_of(v, q % N));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h[q][t] = fmaf(w[t], vq, h[q][t]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h[q][t] = fmaxf(h[q][t], 0.0f);
+  }
+  const f4* p = wq + (2 + d) * 64;
+  f4 acc[Q];
+  for (int m = 1; m <= M; ++m) {               // M-1 hidden 16x16 layers + the 16x16 output layer
+    const f4 A = p[lane];
+    const f4 bias = p[64 + lane];
+    p += 128;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = bias;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t], h[q][t], acc[q], 0, 0, 0);
+    }
+    if (m < M) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h[q][t] = fmaxf(acc[q][t], 0.0f);
+      }
+    }
+  }
+  // exit: acc[q][r] = theta[4g + r] of group q's sample s  ->  th[j] of the lane's own sample(s)
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x0 = acc[0 * N + n][r], x1 = acc[1 * N + n][r], x2 = acc[2 * N + n][r], x3 = acc[3 * N + n][r];
+      transpose4(x0, x1, x2, x3);              // x_g = theta[4g + r] of this lane's sample (component n)
+      set_comp(th[0 + r], n, x0); set_comp(th[4 + r], n, x1);
+      set_comp(th[8 + r], n, x2); set_comp(th[12 + r], n, x3);
+    }
+  }
+}
+
+// floats of one conditioner's MFMA-layout block: (1+d) W0 rows, b0, M x {A, bias}, 64 lanes x 4
+__host__ __device__ inline int64_t cond_floats_mfma(int d, int M) { return 256 * (int64_t)((1 + d) + 1 + 2 * M); }
 
 __host__ __device__ inline int64_t cond_floats(int d, int H, int M, int P) {
   return (int64_t)(1 + d) * H + H + (int64_t)(M - 1) * (H * H + H) + (int64_t)H * P + P;

@@ -32,7 +32,9 @@ enum AuxMode { AUX_LOGDET = 0, AUX_LOGPROB = 1 };
 
 struct ModelArgs {
   const float* prep;     // prepared model buffer
+  const float* wq;       // MFMA-layout weights (inside prep), or null
   int64_t per_layer;     // floats of conditioner weights per flow layer
+  int64_t per_layer_q;   // floats of MFMA-layout weights per flow layer
   int32_t D, L, M;
   SplineConsts sc;
 };
@@ -46,6 +48,7 @@ struct FlowArgs {
   int64_t B;
   int64_t c_block;
   int32_t c_mode, aux_mode;
+  int32_t div_magic;     // ceil(2^32 / D): e / D == umulhi(e, magic) for e < 2^16
 };
 
 // ---------------------------------------------------------------------------
@@ -55,12 +58,40 @@ struct FlowArgs {
 // ---------------------------------------------------------------------------
 __global__ void prepare_kernel(const float* __restrict__ params, float* __restrict__ prep,
                                int K, int64_t n_params, double lo, double hi, double min_bin,
-                               double min_slope) {
+                               double min_slope, int D, int L, int M, int64_t per_layer,
+                               int64_t per_layer_q, int64_t mfma_off) {
   const int P = 3 * K + 1;
   const int hdr = hdr_floats(K);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_params - P;
        i += (int64_t)gridDim.x * blockDim.x)
     prep[hdr + i] = params[P + i];
+  if (mfma_off > 0) {
+    // MFMA-layout copy of every conditioner (H = P = 16): see conditioner_mfma.
+    const int nc = L * (D - 1);
+    for (int ci = blockIdx.x; ci < nc; ci += gridDim.x) {
+      const int l = ci / (D - 1), d = 1 + ci % (D - 1);
+      int64_t so = P + l * per_layer, qo = mfma_off + l * per_layer_q;
+      for (int dd = 1; dd < d; ++dd) { so += cond_floats(dd, 16, M, 16); qo += cond_floats_mfma(dd, M); }
+      const float* src = params + so;
+      float* dst = prep + qo;
+      const int nf = (1 + d) + 1 + 2 * M;
+      for (int idx = threadIdx.x; idx < nf * 64; idx += blockDim.x) {
+        const int f = idx >> 6, lane = idx & 63, g = lane >> 4, i = lane & 15;
+        float o[4];
+        if (f <= d) {                         // W0 row f (f = 0: the c row)
+          for (int t = 0; t < 4; ++t) o[t] = src[f * 16 + 4 * g + t];
+        } else if (f == d + 1) {              // b0
+          for (int t = 0; t < 4; ++t) o[t] = src[(1 + d) * 16 + 4 * g + t];
+        } else {
+          const int m = (f - (d + 2)) >> 1;
+          const float* Wm = src + (1 + d) * 16 + 16 + m * (256 + 16);
+          if (((f - (d + 2)) & 1) == 0) { for (int t = 0; t < 4; ++t) o[t] = Wm[(4 * g + t) * 16 + i]; }   // A step t
+          else { for (int t = 0; t < 4; ++t) o[t] = Wm[256 + 4 * g + t]; }                               // bias rows 4g+r
+        }
+        for (int t = 0; t < 4; ++t) dst[(f * 64 + lane) * 4 + t] = o[t];
+      }
+    }
+  }
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
 
   constexpr int MAXK = 64;
@@ -117,22 +148,24 @@ __global__ void prepare_kernel(const float* __restrict__ params, float* __restri
 // is U[d*TS + SPL*t] (one ds_read_b32 / ds_read_b64 per dimension,
 // conflict-free).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void tile_load(const float* __restrict__ g, float* U, int D, int TS,
+// e / D for e < 2^16 (a tile has at most 512 * 64 elements): one v_mul_hi_u32
+// instead of the ~20-instruction 32-bit division sequence.
+__device__ __forceinline__ void tile_load(const float* __restrict__ g, float* U, int D, uint32_t magic, int TS,
                                           int64_t tile_start, int64_t B) {
   const int64_t base = tile_start * D;
-  const int64_t n_el = (B - tile_start < TS ? B - tile_start : TS) * (int64_t)D;
+  const int n_el = (int)(B - tile_start < TS ? B - tile_start : TS) * D;
   for (int e = threadIdx.x; e < TS * D; e += TILE) {
-    const int s = e / D, d = e - s * D;
+    const int s = magic ? (int)__umulhi((uint32_t)e, magic) : e, d = e - s * D;   // magic 0: D = 1
     U[d * TS + s] = e < n_el ? g[base + e] : 0.0f;
   }
 }
 
-__device__ __forceinline__ void tile_store(float* __restrict__ g, const float* U, int D, int TS,
+__device__ __forceinline__ void tile_store(float* __restrict__ g, const float* U, int D, uint32_t magic, int TS,
                                            int64_t tile_start, int64_t B) {
   const int64_t base = tile_start * D;
-  const int64_t n_el = (B - tile_start < TS ? B - tile_start : TS) * (int64_t)D;
+  const int n_el = (int)(B - tile_start < TS ? B - tile_start : TS) * D;
   for (int e = threadIdx.x; e < TS * D; e += TILE) {
-    const int s = e / D, d = e - s * D;
+    const int s = magic ? (int)__umulhi((uint32_t)e, magic) : e, d = e - s * D;
     if (e < n_el) g[base + e] = U[d * TS + s];
   }
 }
@@ -163,8 +196,9 @@ __device__ __forceinline__ v2f hsum(v2f v) { return v; }
 // TO_BASE=true : data -> base (chain.forward, spline forward, conditions on
 // already-produced outputs: conditional.py:159-167, autoregressive.py:76-107).
 // Returns the accumulated log|det J|; the result is left in `U` (swapped).
-template <int H, int K, bool TO_BASE, bool FAST, class T>
+template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false>
 __device__ __forceinline__ T flow_pass(const ModelArgs& a, const float* tab, float*& U, float*& O, T c) {
+  static_assert(!MFMA || (H == 16 && K == 5), "the MFMA conditioner is built for H = 16, P = 16");
   constexpr int P = 3 * K + 1;
   constexpr bool INV = !TO_BASE;
   constexpr int SPL = Lanes<T>::N;
@@ -183,14 +217,20 @@ __device__ __forceinline__ T flow_pass(const ModelArgs& a, const float* tab, flo
     lds_put(co, first_idx, TS, o);
     acc += ld;
     uniform_ptr w = weights + l * a.per_layer;
+    const float* wq = a.wq + l * a.per_layer_q;
     for (int d = 1; d < D; ++d) {
       const int i = first_idx + d * idx_step;
       T th[P];
-      conditioner<H, P, T>(w, d, a.M, c, TO_BASE ? co : cu, first_idx, idx_step, TS, th);
+      if constexpr (MFMA) {
+        conditioner_mfma<T>(reinterpret_cast<const f4*>(wq), d, a.M, c, TO_BASE ? co : cu, first_idx, idx_step, TS, th);
+        wq += cond_floats_mfma(d, a.M);
+      } else {
+        conditioner<H, P, T>(w, d, a.M, c, TO_BASE ? co : cu, first_idx, idx_step, TS, th);
+        w += cond_floats(d, H, a.M, P);
+      }
       cond_spline<K, INV, FAST, T>(th, lds_get<T>(cu, i, TS), a.sc, o, ld);
       lds_put(co, i, TS, o);
       acc += ld;
-      w += cond_floats(d, H, a.M, P);
     }
     float* t = U; U = O; O = t;
   }
@@ -212,8 +252,8 @@ __device__ __forceinline__ void store_aux(float* aux, int64_t i, int64_t B, v2f 
   else { if (i < B) aux[i] = r.x; if (i + 1 < B) aux[i + 1] = r.y; }
 }
 
-template <int H, int K, bool TO_BASE, bool FAST, class T>
-__global__ __launch_bounds__(TILE) void flow_kernel(const FlowArgs a) {
+template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false>
+__global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HDR = hdr_floats(K);
   constexpr int SPL = Lanes<T>::N;
@@ -228,13 +268,13 @@ __global__ __launch_bounds__(TILE) void flow_kernel(const FlowArgs a) {
     const int64_t tile_start = tile * TS;
     const int64_t i = tile_start + SPL * threadIdx.x;
     __syncthreads();                       // previous tile's stores are done with U/O
-    tile_load(a.in, U, a.m.D, TS, tile_start, a.B);
+    tile_load(a.in, U, a.m.D, a.div_magic, TS, tile_start, a.B);
     const T c = load_cond<T>(a, tile_start, i);
     __syncthreads();
 
     T base = splat<T>(0.0f);
     if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = base_logprob<T>(U + SPL * threadIdx.x, a.m.D, TS);
-    const T acc = flow_pass<H, K, TO_BASE, FAST, T>(a.m, tab, U, O, c);
+    const T acc = flow_pass<H, K, TO_BASE, FAST, T, MFMA>(a.m, tab, U, O, c);
     if (a.aux) {
       T r = acc;
       if (a.aux_mode == AUX_LOGPROB) {
@@ -245,7 +285,7 @@ __global__ __launch_bounds__(TILE) void flow_kernel(const FlowArgs a) {
     }
     if (a.out) {
       __syncthreads();
-      tile_store(a.out, U, a.m.D, TS, tile_start, a.B);
+      tile_store(a.out, U, a.m.D, a.div_magic, TS, tile_start, a.B);
     }
   }
 }
@@ -267,6 +307,7 @@ struct LossArgs {
   int64_t B;            // samples per slice
   int64_t n_slices;
   int64_t pts_slice_stride;   // samples between slices in pts (0: shared draw)
+  uint32_t div_magic;
 };
 
 template <class T>
@@ -322,7 +363,7 @@ __device__ __forceinline__ float mask_tail(v2f v, int64_t i, int64_t B) {
 }
 
 template <int H, int K, bool FAST, class T>
-__global__ __launch_bounds__(TILE) void loss_kernel(const LossArgs a) {
+__global__ __launch_bounds__(TILE, 2) void loss_kernel(const LossArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HDR = hdr_floats(K);
   constexpr int SPL = Lanes<T>::N;
@@ -346,7 +387,7 @@ __global__ __launch_bounds__(TILE) void loss_kernel(const LossArgs a) {
     const int64_t tile_start = (tile - slice * tiles_per_slice) * TS;
     const int64_t i = tile_start + col;
     __syncthreads();
-    tile_load(a.pts + slice * a.pts_slice_stride * D, Nn, D, TS, tile_start, a.B);
+    tile_load(a.pts + slice * a.pts_slice_stride * D, Nn, D, a.div_magic, TS, tile_start, a.B);
     const float t = a.t[slice];
     __syncthreads();
 
@@ -472,6 +513,10 @@ struct CnfModel {
   int num_cus;
   int fast_math;          // 1: hardware transcendentals (default), 0: ocml
   int force_spl;          // 0: automatic; 1 / 2: samples per lane (tests, bench)
+  int use_mfma;           // 1: MFMA conditioner where available (H = 16, K = 5, fast math)
+  uint32_t div_magic;     // ceil(2^32 / D)
+  int64_t per_layer_q;    // MFMA-layout floats per flow layer (0: not available)
+  int64_t mfma_off;       // offset of the MFMA-layout weights inside prep (floats)
   int params_set;
 };
 
@@ -552,7 +597,20 @@ extern "C" int cnf_model_create(const CnfConfig* cfg, CnfModel** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, m->device) != hipSuccess) { delete m; return CNF_ERR_HIP; }
   m->num_cus = prop.multiProcessorCount;
-  const size_t bytes = (size_t)(hdr_floats(K) + (m->n_params - P)) * sizeof(float) + 64;
+  // The MFMA conditioner is built and tested but NOT the default: fp32 MFMA and
+  // fp32 VALU do not overlap on gfx950 (their busy times add up: profiles/r01c),
+  // and at equal peak rate the packed-VALU conditioner is 4-5 % faster.
+  m->use_mfma = 0;
+  // (D = 1 would need 2^32: encoded as 0, tile_load/tile_store take s = e)
+  m->div_magic = cfg->dim == 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + (uint64_t)cfg->dim - 1) / (uint64_t)cfg->dim);
+  m->per_layer_q = 0; m->mfma_off = 0;
+  size_t q_floats = 0;
+  if (cfg->hidden_size == 16 && P == 16 && cfg->dim > 1) {
+    for (int d = 1; d < cfg->dim; ++d) m->per_layer_q += cond_floats_mfma(d, cfg->mlp_num_layers);
+    m->mfma_off = (hdr_floats(K) + (m->n_params - P) + 3) & ~(int64_t)3;
+    q_floats = (size_t)m->per_layer_q * cfg->num_layers;
+  }
+  const size_t bytes = (size_t)(hdr_floats(K) + (m->n_params - P) + 4 + q_floats) * sizeof(float) + 64;
   if (hipMalloc((void**)&m->prep, bytes) != hipSuccess) { delete m; return CNF_ERR_NOMEM; }
   *out = m;
   return CNF_OK;
@@ -572,6 +630,13 @@ extern "C" int cnf_model_set_fast_math(CnfModel* m, int on) {
   return CNF_OK;
 }
 
+/* Internal knob: 1 = MFMA conditioner where available (default), 0 = VALU. */
+extern "C" int cnf_model_set_mfma(CnfModel* m, int on) {
+  if (!m) return CNF_ERR_INVALID;
+  m->use_mfma = on ? 1 : 0;
+  return CNF_OK;
+}
+
 /* Internal knob: 0 = choose by batch size, 1 / 2 = force samples per lane. */
 extern "C" int cnf_model_set_samples_per_lane(CnfModel* m, int spl) {
   if (!m || spl < 0 || spl > 2) return CNF_ERR_INVALID;
@@ -588,7 +653,8 @@ extern "C" int cnf_model_set_params(CnfModel* m, const float* params, void* stre
   if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(prepare_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, m->prep, K,
                      m->n_params, (double)m->cfg.range_min, (double)m->cfg.range_max,
-                     (double)m->cfg.min_bin_size, (double)m->cfg.min_knot_slope);
+                     (double)m->cfg.min_bin_size, (double)m->cfg.min_knot_slope, m->cfg.dim,
+                     m->cfg.num_layers, m->cfg.mlp_num_layers, m->per_layer, m->per_layer_q, m->mfma_off);
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
   m->params_set = 1;
   return CNF_OK;
@@ -597,6 +663,7 @@ extern "C" int cnf_model_set_params(CnfModel* m, const float* params, void* stre
 static ModelArgs model_args(const CnfModel* m) {
   ModelArgs a;
   a.prep = m->prep; a.per_layer = m->per_layer;
+  a.wq = m->mfma_off > 0 ? m->prep + m->mfma_off : nullptr; a.per_layer_q = m->per_layer_q;
   a.D = m->cfg.dim; a.L = m->cfg.num_layers; a.M = m->cfg.mlp_num_layers;
   a.sc = m->sc;
   return a;
@@ -617,6 +684,13 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
   const int64_t cap = (int64_t)m->num_cus * 8;
   if (grid > cap) grid = cap;
   const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * ts) * sizeof(float);
+  if (m->fast_math && m->use_mfma && m->mfma_off > 0 && m->cfg.hidden_size == 16 && m->cfg.num_bins == 5) {
+    if (spl == 2)
+      hipLaunchKernelGGL((flow_kernel<16, 5, TO_BASE, true, v2f, true>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+    else
+      hipLaunchKernelGGL((flow_kernel<16, 5, TO_BASE, true, float, true>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+  }
 #define X(HH, KK)                                                                             \
   if (m->cfg.hidden_size == HH && m->cfg.num_bins == KK) {                                    \
     if (!m->fast_math)                                                                        \
@@ -643,6 +717,7 @@ static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, 
   a.in = in; a.c = c; a.out = out; a.aux = aux;
   a.B = B; a.c_block = c_block;
   a.aux_mode = aux_mode;
+  a.div_magic = m->div_magic;
   const int spl = m->fast_math ? samples_per_lane(m, B) : 1;
   if (c_block >= B) a.c_mode = C_SINGLE;
   else if (c_block == 1) a.c_mode = C_PER_SAMPLE;
@@ -713,6 +788,7 @@ extern "C" int cnf_loss_terms(CnfModel* m, const CnfLossSpec* spec, const float*
   LossArgs a;
   a.m = model_args(m); a.spec = *spec; a.pts = pts; a.t = t; a.sums = sums;
   a.B = B; a.n_slices = n_slices; a.pts_slice_stride = pts_shared ? 0 : B;
+  a.div_magic = m->div_magic;
   // five D x TS buffers: keep a workgroup under ~64 KB of LDS
   int spl = (m->fast_math && n_slices * B >= (int64_t)m->num_cus * 4 * 64 * 2) ? 2 : 1;
   if (m->force_spl == 1 || m->force_spl == 2) spl = m->fast_math ? m->force_spl : 1;

@@ -94,6 +94,11 @@ class FlowEngine:
   def set_fast_math(self, on: bool) -> None:
     _capi.check(self.lib.cnf_model_set_fast_math(self._h, 1 if on else 0), "cnf_model_set_fast_math")
 
+  def set_mfma(self, on: bool) -> None:
+    """MFMA (v_mfma_f32_16x16x4_f32) conditioner where available (hidden 16,
+    5 bins, fast math) -- the default -- or the packed-VALU conditioner."""
+    _capi.check(self.lib.cnf_model_set_mfma(self._h, 1 if on else 0), "cnf_model_set_mfma")
+
   def set_samples_per_lane(self, spl: int) -> None:
     """0: chosen by batch size (default); 1 / 2: force the one-sample or the
     packed two-samples-per-lane kernel."""

@@ -20,4 +20,5 @@ from .capi import (  # noqa: F401
   knots,
   normal,
   num_threads,
+  set_num_threads,
 )

@@ -65,6 +65,10 @@ def load_library():
   return lib
 
 
+def set_num_threads(n: int) -> None:
+  load_library().cnf_oracle_set_num_threads(ctypes.c_int(int(n)))
+
+
 def num_threads() -> int:
   return int(load_library().cnf_oracle_num_threads())
 

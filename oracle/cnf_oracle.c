@@ -30,6 +30,14 @@ size_t cnf_oracle_param_count(const cnf_oracle_cfg *g) {
   return n;
 }
 
+void cnf_oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int cnf_oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -65,6 +65,7 @@ int cnf_oracle_normal_f64(uint64_t seed, uint64_t first_element, int64_t n,
                           double *out);
 
 int cnf_oracle_num_threads(void);
+void cnf_oracle_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -70,17 +70,19 @@ GOLDEN = {
 }
 
 
-@pytest.mark.parametrize("variant", ["packed2", "fast1", "ocml1"])
+@pytest.mark.parametrize("variant", ["mfma2", "mfma1", "packed2", "fast1", "ocml1"])
 @pytest.mark.parametrize("name", sorted(GOLDEN))
 def test_golden_vectors(golden_dir, dev, name, variant):
-  """Every kernel variant: two samples per lane with packed fp32 math (the
-  large-batch default), one sample per lane, and one sample per lane with ocml
-  expf/logf + IEEE division instead of the hardware transcendentals."""
+  """Every kernel variant: MFMA conditioner with two / one samples per lane
+  (the default for the reference's 16-wide network), packed-VALU conditioner,
+  one sample per lane, and ocml expf/logf + IEEE division instead of the
+  hardware transcendentals."""
   fcfg, _ = _cfg_pair(**GOLDEN[name])
   g = np.load(os.path.join(golden_dir, name))
   eng = _engine(fcfg, g["params"], dev)
   eng.set_fast_math(variant != "ocml1")
-  eng.set_samples_per_lane(2 if variant == "packed2" else 1)
+  eng.set_mfma(variant.startswith("mfma"))       # only takes effect for hidden 16 / 5 bins
+  eng.set_samples_per_lane(2 if variant.endswith("2") else 1)
   x = _t(g["noise"], dev)
   for tag, c in (("u", g["c_uniform"]), ("p", g["c_per"])):
     ct = _t(c, dev)
@@ -104,10 +106,11 @@ def test_golden_vectors(golden_dir, dev, name, variant):
   assert _err(lpv, g["lp_value_u"]).max() <= TOL_LP_DATA_MAX
 
 
+@pytest.mark.parametrize("mfma", [True, False], ids=["mfma", "valu"])
 @pytest.mark.parametrize("spl", [1, 2])
 @pytest.mark.parametrize("params_kind", ["zeros", "random"])
 @pytest.mark.parametrize("t", [0.0, 0.5, 1.0])
-def test_config2_batch_65536_vs_oracle(dev, params_kind, t, spl):
+def test_config2_batch_65536_vs_oracle(dev, params_kind, t, spl, mfma):
   """BASELINE config 2 / SURVEY.md 8(d): D=2, B=65 536, base noise N(0,I), c
   uniform t in {0, .5, 1}; params (i) zeros (identity), (ii) N(0, 0.2^2) seed 42."""
   import oracle
@@ -118,10 +121,11 @@ def test_config2_batch_65536_vs_oracle(dev, params_kind, t, spl):
   noise = rng.normal(size=(65536, 2)).astype(np.float32)
   eng = _engine(fcfg, params, dev)
   eng.set_samples_per_lane(spl)
+  eng.set_mfma(mfma)
   y, lp = eng.sample_logprob(_t(noise, dev), torch.tensor([t], device=dev))
   y_ref, lp_ref = oracle.sample_logprob(ocfg, params, noise.astype(np.float64), [t])
   ey, elp = _err(y, y_ref), _err(lp, lp_ref)
-  print(f"\n[cfg2 {params_kind} t={t} spl={spl}] max|dy|={ey.max():.2e} max|dlogp|={elp.max():.2e} "
+  print(f"\n[cfg2 {params_kind} t={t} spl={spl} mfma={mfma}] max|dy|={ey.max():.2e} max|dlogp|={elp.max():.2e} "
         f"p99.9={np.quantile(elp, 0.999):.2e} median={np.median(elp):.2e}")
   assert ey.max() <= TOL_Y
   assert elp.max() <= TOL_LP_SAMPLE
