@@ -57,6 +57,12 @@ SYMBOLS = {
   "cnf_sample_logprob": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
   "cnf_fill_normal": (ctypes.c_int, [_U64, _U64, _I64, _P, _P]),
   "cnf_loss_terms": (ctypes.c_int, [_P, ctypes.POINTER(CnfLossSpec), _P, ctypes.c_int, _P, _I64, _I64, _P, _P]),
+  "cnf_grad_supported": (ctypes.c_int, [_CFG]),
+  "cnf_grad_enable": (ctypes.c_int, [_P, _I64]),
+  "cnf_loss_terms_grad": (ctypes.c_int, [_P, ctypes.POINTER(CnfLossSpec), _P, ctypes.c_int, _P, _I64, _I64,
+                                         ctypes.c_float, _P, _P, _P, _P]),
+  "cnf_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                   ctypes.c_float, _I64, _P]),
   "cnf_strerror": (ctypes.c_char_p, [ctypes.c_int]),
   "cnf_build_arch": (ctypes.c_char_p, []),
   "cnf_config_supported": (ctypes.c_int, [_CFG]),

@@ -56,12 +56,15 @@ def draw_components(rng, n: int) -> np.ndarray:
 
 
 class _Ctx:
-  """Backend (loaded engine) + shard + local noise cache for one loss call."""
+  """Backend (loaded engine) + shard + local noise cache for one loss call.
+  With `grad` (a zeroed flat float32 tensor) every term also accumulates
+  coef * d(term sum)/d(params) into it (cnf_loss_terms_grad)."""
 
-  def __init__(self, model, params, rng, shard: Optional[Shard]):
+  def __init__(self, model, params, rng, shard: Optional[Shard], grad: Optional[torch.Tensor] = None):
     self.be = model.terms_backend(params)
     self.rng = rng
     self.shard = shard if shard is not None else current_shard()
+    self.grad = grad
     self._noise = {}
 
   def noise(self, n_global: int) -> torch.Tensor:
@@ -71,12 +74,22 @@ class _Ctx:
       self._noise[n_global] = (self.be.normal(self.rng, count, first_sample=start), start, count)
     return self._noise[n_global]
 
-  def terms(self, spec, pts, t, B_local, shared=True):
-    return self.be.loss_terms(spec, pts, np.atleast_1d(np.asarray(t, dtype=np.float32)), B_local, shared)
+  def terms(self, spec, pts, t, B_local, coef, shared=True):
+    """per-slice sums of one term; `coef` = d(loss)/d(sum) (the same for every slice)."""
+    t = np.atleast_1d(np.asarray(t, dtype=np.float32))
+    if self.grad is not None:
+      return self.be.loss_terms_grad(spec, pts, t, B_local, shared, coef, self.grad)
+    return self.be.loss_terms(spec, pts, t, B_local, shared)
 
   def reduce(self, sums: Sequence[torch.Tensor]) -> torch.Tensor:
-    flat = torch.cat([s.reshape(-1).to(torch.float64) for s in sums])
-    return all_reduce_sums(flat, self.shard)
+    """The ONE collective of a loss evaluation: partial sums (+ the gradient)."""
+    parts = [s.reshape(-1).to(torch.float64) for s in sums]
+    n = sum(p.numel() for p in parts)
+    if self.grad is not None and self.shard.world > 1:
+      flat = all_reduce_sums(torch.cat(parts + [self.grad.to(torch.float64)]), self.shard)
+      self.grad.copy_(flat[n:].to(torch.float32))
+      return flat[:n]
+    return all_reduce_sums(torch.cat(parts), self.shard)
 
 
 # ---- local partial sums of each term ----------------------------------------
@@ -96,36 +109,36 @@ def _source_samples(ctx, z, start, count, n_global, source):
   raise ValueError(f"unknown source {source!r}")
 
 
-def _kl_sum(ctx, T, cond, batch_size, source):
+def _kl_sum(ctx, T, cond, batch_size, source, coef):
   z, start, count = ctx.noise(batch_size)
   s1 = _source_samples(ctx, z, start, count, batch_size, source)
   samples = s1 * ((T - cond) / T) + z * (cond / T)      # target N(0,I) drawn from the same key
-  return ctx.terms(_spec(_capi.TERM_NEG_LOGPROB), samples.contiguous(), [cond], count)
+  return ctx.terms(_spec(_capi.TERM_NEG_LOGPROB), samples.contiguous(), [cond], count, coef)
 
 
-def _reverse_kl_sum(ctx, T, beta, cond, batch_size):
+def _reverse_kl_sum(ctx, T, beta, cond, batch_size, coef):
   z, _, count = ctx.noise(batch_size)
-  return ctx.terms(_spec(_capi.TERM_REVERSE_KL, T=T, beta=beta), z, [cond], count)
+  return ctx.terms(_spec(_capi.TERM_REVERSE_KL, T=T, beta=beta), z, [cond], count, coef)
 
 
-def _potential_sum(ctx, a, subtype, conds, batch_size):
+def _potential_sum(ctx, a, subtype, conds, batch_size, coef):
   if subtype not in _capi.POTENTIALS:
     raise ValueError(f"unknown potential {subtype!r}")
   z, _, count = ctx.noise(batch_size)
-  return ctx.terms(_spec(_capi.TERM_POTENTIAL, subtype=_capi.POTENTIALS[subtype], a=a), z, conds, count)
+  return ctx.terms(_spec(_capi.TERM_POTENTIAL, subtype=_capi.POTENTIALS[subtype], a=a), z, conds, count, coef)
 
 
-def _kinetic_sum(ctx, dt, conds, batch_size):
+def _kinetic_sum(ctx, dt, conds, batch_size, coef):
   z, _, count = ctx.noise(batch_size)
-  return ctx.terms(_spec(_capi.TERM_KINETIC, dt=dt), z, conds, count)
+  return ctx.terms(_spec(_capi.TERM_KINETIC, dt=dt), z, conds, count, coef)
 
 
-def _kinetic_score_sum(ctx, beta, dt, dx, conds, batch_size):
+def _kinetic_score_sum(ctx, beta, dt, dx, conds, batch_size, coef):
   z, _, count = ctx.noise(batch_size)
-  return ctx.terms(_spec(_capi.TERM_KINETIC_SCORE, dt=dt, dx=dx, coef=1.0 / beta), z, conds, count)
+  return ctx.terms(_spec(_capi.TERM_KINETIC_SCORE, dt=dt, dx=dx, coef=1.0 / beta), z, conds, count, coef)
 
 
-def _flow_matching_sum(ctx, dim, a, sigma, subtype, conds, batch_size):
+def _flow_matching_sum(ctx, dim, a, sigma, subtype, conds, batch_size, coef):
   if subtype not in _capi.DRIFTS:
     raise ValueError(f"unknown velocity field {subtype!r}")
   if subtype in ("nongradient",) and dim != 2:
@@ -138,94 +151,120 @@ def _flow_matching_sum(ctx, dim, a, sigma, subtype, conds, batch_size):
   z, _, count = ctx.noise(batch_size)
   # dt and dx are overridden to 0.01 inside the reference function (:286,301)
   return ctx.terms(_spec(_capi.TERM_FLOW_MATCHING, subtype=_capi.DRIFTS[subtype], dt=0.01, dx=0.01,
-                         coef=sigma, a=a), z, conds, count)
+                         coef=sigma, a=a), z, conds, count, coef)
 
 
 # ---- public term functions (reference signatures) ----------------------------
+# Every function takes two extra keywords: `shard` (cnf_ot_amd.distributed.Shard,
+# default: the torch.distributed world) and `grad` (a zeroed flat float32 tensor
+# that receives d loss / d params: see `value_and_grad`).
 
-def kl_loss_fn(model, dim, T, params, cond, rng, batch_size, source="mixture", shard=None):
+def kl_loss_fn(model, dim, T, params, cond, rng, batch_size, source="mixture", shard=None, grad=None):
   """applications.py:11-86: -mean log_prob of samples interpolated between the
   source and the target draw."""
-  ctx = _Ctx(model, params, rng, shard)
-  return ctx.reduce([_kl_sum(ctx, T, float(cond), batch_size, source)])[0] / batch_size
+  ctx = _Ctx(model, params, rng, shard, grad)
+  return ctx.reduce([_kl_sum(ctx, T, float(cond), batch_size, source, 1.0 / batch_size)])[0] / batch_size
 
 
-def density_fit_kl_loss_fn(model, dim, T, params, rng, batch_size, source="mixture", shard=None):
+def density_fit_kl_loss_fn(model, dim, T, params, rng, batch_size, source="mixture", shard=None, grad=None):
   """applications.py:166-173"""
-  ctx = _Ctx(model, params, rng, shard)
-  s = ctx.reduce([_kl_sum(ctx, T, 0.0, batch_size, source), _kl_sum(ctx, T, float(T), batch_size, source)])
-  return (s[0] + s[1]) / batch_size
+  ctx = _Ctx(model, params, rng, shard, grad)
+  c = 1.0 / batch_size
+  s = ctx.reduce([_kl_sum(ctx, T, 0.0, batch_size, source, c), _kl_sum(ctx, T, float(T), batch_size, source, c)])
+  return (s[0] + s[1]) * c
 
 
-def reverse_kl_loss_fn(model, dim, T, beta, params, cond, rng, batch_size, shard=None):
+def reverse_kl_loss_fn(model, dim, T, beta, params, cond, rng, batch_size, shard=None, grad=None):
   """applications.py:129-163"""
-  ctx = _Ctx(model, params, rng, shard)
-  return ctx.reduce([_reverse_kl_sum(ctx, T, beta, float(cond), batch_size)])[0] / batch_size
+  ctx = _Ctx(model, params, rng, shard, grad)
+  return ctx.reduce([_reverse_kl_sum(ctx, T, beta, float(cond), batch_size, 1.0 / batch_size)])[0] / batch_size
 
 
-def potential_loss_fn(model, dim, a, subtype, params, cond, rng, batch_size, shard=None):
+def potential_loss_fn(model, dim, a, subtype, params, cond, rng, batch_size, shard=None, grad=None):
   """applications.py:176-205"""
-  ctx = _Ctx(model, params, rng, shard)
-  return ctx.reduce([_potential_sum(ctx, a, subtype, [float(cond)], batch_size)])[0] / batch_size
+  ctx = _Ctx(model, params, rng, shard, grad)
+  return ctx.reduce([_potential_sum(ctx, a, subtype, [float(cond)], batch_size, 1.0 / batch_size)])[0] / batch_size
 
 
-def kinetic_loss_fn(model, dim, dt, params, cond, rng, batch_size, shard=None):
+def kinetic_loss_fn(model, dim, dt, params, cond, rng, batch_size, shard=None, grad=None):
   """applications.py:220-242: mean(v^2) * dim / 2 with v by finite differences in c."""
-  ctx = _Ctx(model, params, rng, shard)
-  return ctx.reduce([_kinetic_sum(ctx, dt, [float(cond)], batch_size)])[0] / (batch_size * dim) * dim / 2
+  ctx = _Ctx(model, params, rng, shard, grad)
+  c = 0.5 / batch_size       # mean over batch*dim, times dim / 2
+  return ctx.reduce([_kinetic_sum(ctx, dt, [float(cond)], batch_size, c)])[0] * c
 
 
-def kinetic_with_score_loss_fn(model, dim, beta, dt, dx, params, cond, rng, batch_size, shard=None):
+def kinetic_with_score_loss_fn(model, dim, beta, dt, dx, params, cond, rng, batch_size, shard=None, grad=None):
   """applications.py:245-276"""
-  ctx = _Ctx(model, params, rng, shard)
-  return ctx.reduce([_kinetic_score_sum(ctx, beta, dt, dx, [float(cond)], batch_size)])[0] / (batch_size * dim) * dim / 2
+  ctx = _Ctx(model, params, rng, shard, grad)
+  c = 0.5 / batch_size
+  return ctx.reduce([_kinetic_score_sum(ctx, beta, dt, dx, [float(cond)], batch_size, c)])[0] * c
 
 
-def flow_matching_loss_fn(model, dim, a, sigma, subtype, dt, dx, params, cond, rng, batch_size, shard=None):
+def flow_matching_loss_fn(model, dim, a, sigma, subtype, dt, dx, params, cond, rng, batch_size, shard=None,
+                          grad=None):
   """applications.py:279-374 (dt, dx arguments are ignored, as in the reference)."""
-  ctx = _Ctx(model, params, rng, shard)
-  return ctx.reduce([_flow_matching_sum(ctx, dim, a, sigma, subtype, [float(cond)], batch_size)])[0] / (batch_size * dim) * dim / 2
+  ctx = _Ctx(model, params, rng, shard, grad)
+  c = 0.5 / batch_size
+  return ctx.reduce([_flow_matching_sum(ctx, dim, a, sigma, subtype, [float(cond)], batch_size, c)])[0] * c
 
 
 # ---- composite losses ---------------------------------------------------------
 
 def ot_loss_fn(model, dim, T, dt, t_batch_size, subtype, params, rng, _lambda, batch_size,
-               source="mixture", shard=None):
+               source="mixture", shard=None, grad=None):
   """applications.py:377-402"""
-  ctx = _Ctx(model, params, rng, shard)
+  ctx = _Ctx(model, params, rng, shard, grad)
   t_batch = draw_t_batch(rng, t_batch_size)
   sub = batch_size // 32
-  sums = [_kl_sum(ctx, T, 0.0, batch_size, source), _kl_sum(ctx, T, float(T), batch_size, source),
-          _kinetic_sum(ctx, dt, t_batch, sub)]
-  if subtype == "obstacle":
-    sums.append(_potential_sum(ctx, 0.0, "obstacle", t_batch, sub))
-  s = ctx.reduce(sums)
-  loss = _lambda * (s[0] + s[1]) / batch_size
-  loss = loss + s[2:2 + t_batch_size].sum() / (sub * dim) * dim / 2 / t_batch_size
+  c_kl, c_kin = _lambda / batch_size, 0.5 / (sub * t_batch_size)
+  sums = [_kl_sum(ctx, T, 0.0, batch_size, source, c_kl), _kl_sum(ctx, T, float(T), batch_size, source, c_kl),
+          _kinetic_sum(ctx, dt, t_batch, sub, c_kin)]
   if subtype == "obstacle":      # summed, not averaged, over slices (applications.py:397-400)
+    sums.append(_potential_sum(ctx, 0.0, "obstacle", t_batch, sub, 1.0 / sub))
+  s = ctx.reduce(sums)
+  loss = c_kl * (s[0] + s[1]) + c_kin * s[2:2 + t_batch_size].sum()
+  if subtype == "obstacle":
     loss = loss + s[2 + t_batch_size:].sum() / sub
   return loss
 
 
 def rwpo_loss_fn(model, dim, T, beta, dt, dx, t_batch_size, subtype, a, params, rng, _lambda, batch_size,
-                 shard=None):
+                 shard=None, grad=None):
   """applications.py:405-421"""
-  ctx = _Ctx(model, params, rng, shard)
+  ctx = _Ctx(model, params, rng, shard, grad)
   t_batch = draw_t_batch(rng, t_batch_size, T)
   sub = batch_size // 32
-  s = ctx.reduce([_reverse_kl_sum(ctx, T, beta, 0.0, batch_size),
-                  _potential_sum(ctx, a, subtype, [float(T)], batch_size),
-                  _kinetic_score_sum(ctx, beta, dt, dx, t_batch, sub)])
-  loss = _lambda * s[0] / batch_size + s[1] / batch_size
-  return loss + s[2:].sum() / (sub * dim) * dim / 2 / t_batch_size * T
+  c_rkl, c_pot, c_kin = _lambda / batch_size, 1.0 / batch_size, 0.5 * T / (sub * t_batch_size)
+  s = ctx.reduce([_reverse_kl_sum(ctx, T, beta, 0.0, batch_size, c_rkl),
+                  _potential_sum(ctx, a, subtype, [float(T)], batch_size, c_pot),
+                  _kinetic_score_sum(ctx, beta, dt, dx, t_batch, sub, c_kin)])
+  return c_rkl * s[0] + c_pot * s[1] + c_kin * s[2:].sum()
 
 
 def fp_loss_fn(model, dim, T, a, sigma, dt, dx, t_batch_size, subtype, params, rng, _lambda, batch_size,
-               shard=None):
+               shard=None, grad=None):
   """applications.py:424-441 (beta = 4: the initial Gaussian has variance 1, :432)"""
-  ctx = _Ctx(model, params, rng, shard)
+  ctx = _Ctx(model, params, rng, shard, grad)
   t_batch = draw_t_batch(rng, t_batch_size, T)
   sub = batch_size // 32
-  s = ctx.reduce([_reverse_kl_sum(ctx, T, 4.0, 0.0, batch_size),
-                  _flow_matching_sum(ctx, dim, a, sigma, subtype, t_batch, sub)])
-  return _lambda * s[0] / batch_size + s[1:].sum() / (sub * dim) * dim / 2 / t_batch_size * T
+  c_rkl, c_fm = _lambda / batch_size, 0.5 * T / (sub * t_batch_size)
+  s = ctx.reduce([_reverse_kl_sum(ctx, T, 4.0, 0.0, batch_size, c_rkl),
+                  _flow_matching_sum(ctx, dim, a, sigma, subtype, t_batch, sub, c_fm)])
+  return c_rkl * s[0] + c_fm * s[1:].sum()
+
+
+def value_and_grad(loss_fn):
+  """jax.value_and_grad(loss_fn) of cnf_ot/mfc/solvers.py:94 for the loss
+  functions of this module (bound with functools.partial like the reference
+  does): returns f(params, *args, **kw) -> (loss, grads) with `grads` a
+  `Params` tree (haiku names) over one flat gradient tensor."""
+  from .params import Params
+
+  def wrapped(params, *args, **kw):
+    if not isinstance(params, Params) or not params.flat.is_cuda:
+      raise TypeError("value_and_grad needs device-resident cnf_ot_amd.Params")
+    g = torch.zeros_like(params.flat)
+    loss = loss_fn(params, *args, grad=g, **kw)
+    return loss, Params(params.cfg, g)
+
+  return wrapped

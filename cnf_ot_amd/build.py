@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcnf_ot_amd.so")
-SOURCES = ["cnf_flow.hip"]
-HEADERS = ["cnf_device.h", os.path.join("..", "..", "include", "cnf_ot_amd.h")]
+SOURCES = ["cnf_flow.hip", "cnf_grad.hip"]
+HEADERS = ["cnf_device.h", "cnf_common.h", "cnf_backward.h", os.path.join("..", "..", "include", "cnf_ot_amd.h")]
 ARCH = "gfx950"
 
 

@@ -1,0 +1,343 @@
+// cnf_backward.h -- reverse-mode derivatives of the conditional RQS flow for the
+// reference's network (hidden 16, 2 hidden layers, 5 bins => P = 16), one
+// sample per lane.  Replaces jax.value_and_grad over cnf_ot/mfc/solvers.py:94.
+//
+// The weight gradients are batch reductions  dW[i][j] = sum_samples h_i * g_j :
+// GEMMs whose K dimension is the batch, so they run on the matrix cores
+// (v_mfma_f32_16x16x4_f32, exact fp32): the per-sample operands are staged
+// through LDS into MFMA layout, 4 samples per instruction.
+#pragma once
+
+#include "cnf_common.h"
+
+namespace cnf {
+
+// ---------------------------------------------------------------------------
+// Partials of the forward spline map f(x; bin) and of its log-derivative
+// ld(x; bin) = log f'(x) with respect to x and the bin's six quantities
+// (x0, y0, bw, bh, d0, d1).  f_y0 = 1 and ld_y0 = 0 are implicit.
+// Notation of SURVEY.md Appendix A: z = (x-x0)/bw, s = bh/bw, q = z(1-z),
+// den = s + (d0+d1-2s) q, N = s z^2 + d0 q, f = y0 + bh N / den,
+// A = d1 z^2 + 2 s q + d0 (1-z)^2, ld = 2 log s + log A - 2 log den.
+// ---------------------------------------------------------------------------
+struct BinPartials {
+  float f_x, f_x0, f_bw, f_bh, f_d0, f_d1;
+  float l_x, l_x0, l_bw, l_bh, l_d0, l_d1;
+};
+
+__device__ __forceinline__ BinPartials rqs_partials(float x, float x0, float bw, float bh, float d0,
+                                                    float d1, float lo, float hi) {
+  BinPartials p;
+  const float ibw = 1.0f / bw;
+  const float z = clip01((x - x0) * ibw);
+  const float s = bh * ibw;
+  const float q = z - z * z, qp = 1.0f - 2.0f * z, omz = 1.0f - z;
+  const float st = d0 + d1 - 2.0f * s;
+  const float Nn = fmaf(s * z, z, d0 * q);
+  const float den = fmaf(st, q, s);
+  const float iden = 1.0f / den;
+  const float A = fmaf(d1 * z, z, fmaf(2.0f * s, q, d0 * omz * omz));
+  const float iA = 1.0f / A;
+  const float iden2 = iden * iden;
+  p.f_x = s * s * A * iden2;
+  const float f_s = bh * (z * z * den - Nn * (1.0f - 2.0f * q)) * iden2;
+  p.f_d0 = bh * q * (den - Nn) * iden2;
+  p.f_d1 = -bh * Nn * q * iden2;
+  p.f_x0 = -p.f_x;
+  p.f_bw = -p.f_x * z - f_s * s * ibw;
+  p.f_bh = Nn * iden + f_s * ibw;
+  const float Az = 2.0f * (d1 * z + s * qp - d0 * omz);
+  const float denz = st * qp;
+  const float l_z = Az * iA - 2.0f * denz * iden;
+  const float l_s = 2.0f / s + 2.0f * q * iA - 2.0f * (1.0f - 2.0f * q) * iden;
+  p.l_x = l_z * ibw;
+  p.l_x0 = -p.l_x;
+  p.l_bw = -(l_z * z + l_s * s) * ibw;
+  p.l_bh = l_s * ibw;
+  p.l_d0 = omz * omz * iA - 2.0f * q * iden;
+  p.l_d1 = z * z * iA - 2.0f * q * iden;
+  if (x <= lo) {        // linear tail through (lo, lo) with slope d0 of bin 0
+    p = BinPartials{d0, 0.f, 0.f, 0.f, x - lo, 0.f, 0.f, 0.f, 0.f, 0.f, 1.0f / d0, 0.f};
+  }
+  if (x >= hi) {        // linear tail through (hi, hi) with slope d1 of the last bin
+    p = BinPartials{d1, 0.f, 0.f, 0.f, 0.f, x - hi, 0.f, 0.f, 0.f, 0.f, 0.f, 1.0f / d1};
+  }
+  return p;
+}
+
+// Adjoints of the bin quantities from the adjoints (o_bar, l_bar) of the
+// spline's (output, logdet).  INV=false: out = f(v).  INV=true: out = f^-1(v),
+// logdet = -ld(out): by the implicit function theorem, with the partials taken
+// at x = out,  v_bar = (o_bar - l_bar l_x) / f_x,  p_bar = -(f_p v_bar + l_bar l_p).
+struct BinAdjoint { float v, x0, y0, bw, bh, d0, d1; };
+
+template <bool INV>
+__device__ __forceinline__ BinAdjoint bin_adjoint(const BinPartials& p, float o_bar, float l_bar) {
+  BinAdjoint a;
+  if (!INV) {
+    a.v = o_bar * p.f_x + l_bar * p.l_x;
+    a.x0 = o_bar * p.f_x0 + l_bar * p.l_x0;
+    a.y0 = o_bar;
+    a.bw = o_bar * p.f_bw + l_bar * p.l_bw;
+    a.bh = o_bar * p.f_bh + l_bar * p.l_bh;
+    a.d0 = o_bar * p.f_d0 + l_bar * p.l_d0;
+    a.d1 = o_bar * p.f_d1 + l_bar * p.l_d1;
+  } else {
+    a.v = (o_bar - l_bar * p.l_x) / p.f_x;
+    a.x0 = -(p.f_x0 * a.v + l_bar * p.l_x0);
+    a.y0 = -a.v;
+    a.bw = -(p.f_bw * a.v + l_bar * p.l_bw);
+    a.bh = -(p.f_bh * a.v + l_bar * p.l_bh);
+    a.d0 = -(p.f_d0 * a.v + l_bar * p.l_d0);
+    a.d1 = -(p.f_d1 * a.v + l_bar * p.l_d1);
+  }
+  return a;
+}
+
+// ---------------------------------------------------------------------------
+// Backward of the spline of the shared `first` parameters.  The table holds
+// the normalised knots; the softmax / softplus Jacobians are linear in the
+// per-bin adjoint sums, so a lane only accumulates  Wb[j] (adjoint of width j),
+// Hb[j], Db[j] (adjoint of slope j);  grad_finish_kernel applies the Jacobians
+// once, in float64.
+// ---------------------------------------------------------------------------
+template <int K, bool INV>
+__device__ __forceinline__ float table_spline_bwd(const float* tab, float v, float out, float o_bar, float l_bar,
+                                                  const SplineConsts& sc, float (&Wb)[K], float (&Hb)[K],
+                                                  float (&Db)[K + 1]) {
+  const float* pos = tab + tab_off(INV ? F_YK : F_XK, K);
+  const int k = bin_of<K>(pos, v);
+  const float x = INV ? out : v;
+  const BinPartials p = rqs_partials(x, gather<K>(tab, F_X0, k), gather<K>(tab, F_BW, k), gather<K>(tab, F_BH, k),
+                                     gather<K>(tab, F_D0, k), gather<K>(tab, F_D1, k), sc.lo, sc.hi);
+  const BinAdjoint a = bin_adjoint<INV>(p, o_bar, l_bar);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    Wb[j] += (j < k ? a.x0 : 0.0f) + (j == k ? a.bw : 0.0f);
+    Hb[j] += (j < k ? a.y0 : 0.0f) + (j == k ? a.bh : 0.0f);
+  }
+#pragma unroll
+  for (int j = 0; j <= K; ++j) Db[j] += (j == k ? a.d0 : 0.0f) + (j == k + 1 ? a.d1 : 0.0f);
+  return a.v;
+}
+
+// ---------------------------------------------------------------------------
+// Backward of a conditioner-parameterised spline: recomputes the
+// normalisation of cond_spline (same selection), returns the adjoint of the
+// spline input and writes theta_bar[3K+1].
+// ---------------------------------------------------------------------------
+template <int K, bool INV, bool FAST>
+__device__ __forceinline__ float cond_spline_bwd(const float (&th)[3 * K + 1], float v, float out, float o_bar,
+                                                 float l_bar, const SplineConsts& sc, float (&tb)[3 * K + 1]) {
+  using M = Math<FAST>;
+  float mw = th[0], mh = th[K];
+#pragma unroll
+  for (int k = 1; k < K; ++k) { mw = fmaxf(mw, th[k]); mh = fmaxf(mh, th[K + k]); }
+  float pw[K], ph[K];
+  float sw = 0.0f, sh = 0.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    pw[k] = M::exp(th[k] - mw); ph[k] = M::exp(th[K + k] - mh);
+    sw += pw[k]; sh += ph[k];
+  }
+  const float isw = 1.0f / sw, ish = 1.0f / sh;
+#pragma unroll
+  for (int k = 0; k < K; ++k) { pw[k] *= isw; ph[k] *= ish; }      // softmax probabilities
+  float px = sc.lo, py = sc.lo;
+  float wk = fmaf(pw[0], sc.span_eff, sc.min_bin), hk = fmaf(ph[0], sc.span_eff, sc.min_bin);
+  float x0 = px, y0 = py, bw = wk, bh = hk, t0 = th[2 * K], t1 = th[2 * K + 1];
+  float cumw = 0.0f, cumh = 0.0f, pkw = pw[0], pkh = ph[0], cw = 0.0f, ch = 0.0f;
+  int kk = 0;
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    px += wk; py += hk;
+    cw += pw[k - 1]; ch += ph[k - 1];
+    if (k == K - 1) { wk = sc.hi - px; hk = sc.hi - py; }
+    else { wk = fmaf(pw[k], sc.span_eff, sc.min_bin); hk = fmaf(ph[k], sc.span_eff, sc.min_bin); }
+    const bool ge = INV ? (v >= py) : (v >= px);
+    x0 = ge ? px : x0; y0 = ge ? py : y0; bw = ge ? wk : bw; bh = ge ? hk : bh;
+    t0 = ge ? th[2 * K + k] : t0; t1 = ge ? th[2 * K + k + 1] : t1;
+    cumw = ge ? cw : cumw; cumh = ge ? ch : cumh; pkw = ge ? pw[k] : pkw; pkh = ge ? ph[k] : pkh;
+    kk += ge ? 1 : 0;
+  }
+  const float d0 = knot_slope<FAST, float>(t0, sc), d1 = knot_slope<FAST, float>(t1, sc);
+  const BinPartials p = rqs_partials(INV ? out : v, x0, bw, bh, d0, d1, sc.lo, sc.hi);
+  const BinAdjoint a = bin_adjoint<INV>(p, o_bar, l_bar);
+  // widths: w_j = span p_j + min_bin, x0 = lo + sum_{j<k} w_j, bw = w_k
+  //   theta_bar_j = span p_j (wbar_j - sum_i wbar_i p_i)
+  const float Sw = a.x0 * cumw + a.bw * pkw, Sh = a.y0 * cumh + a.bh * pkh;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const float wb = (j < kk ? a.x0 : 0.0f) + (j == kk ? a.bw : 0.0f);
+    const float hb = (j < kk ? a.y0 : 0.0f) + (j == kk ? a.bh : 0.0f);
+    tb[j] = sc.span_eff * pw[j] * (wb - Sw);
+    tb[K + j] = sc.span_eff * ph[j] * (hb - Sh);
+  }
+  // slopes: d = softplus(t + off) + m  =>  dd/dt = sigmoid(t + off)
+  const float sg0 = 1.0f / (1.0f + M::exp(-(t0 + sc.sp_offset)));
+  const float sg1 = 1.0f / (1.0f + M::exp(-(t1 + sc.sp_offset)));
+#pragma unroll
+  for (int j = 0; j <= K; ++j) tb[2 * K + j] = (j == kk ? a.d0 * sg0 : 0.0f) + (j == kk + 1 ? a.d1 * sg1 : 0.0f);
+  return a.v;
+}
+
+// ---------------------------------------------------------------------------
+// Conditioner forward that keeps the hidden activations (M = 2, H = P = 16).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void conditioner_keep(uniform_ptr w, int d, float c, const float* col, int first_idx,
+                                                 int idx_step, int stride, float (&h1)[16], float (&h2)[16],
+                                                 float (&th)[16]) {
+  w = launder(w);
+  uniform_ptr b0 = w + (1 + d) * 16;
+  {
+    float wc[16], bb[16];
+    load_row<16>(w, wc); load_row<16>(b0, bb);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h1[j] = fmaf(wc[j], c, bb[j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int q = 0; q < d; ++q) {
+    const float v = col[(first_idx + q * idx_step) * stride];
+    float wr[16];
+    load_row<16>(w + (1 + q) * 16, wr);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h1[j] = fmaf(wr[j], v, h1[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) h1[j] = fmaxf(h1[j], 0.0f);
+  materialize<16>(h1);
+  w = b0 + 16;
+  {
+    float bb[16];
+    load_row<16>(w + 256, bb);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h2[j] = bb[j];
+    __builtin_amdgcn_sched_barrier(0);
+    dense_acc<16, 16, 1, float>(w, h1, h2);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h2[j] = fmaxf(h2[j], 0.0f);
+    materialize<16>(h2);
+  }
+  w += 256 + 16;
+  {
+    float bb[16];
+    load_row<16>(w + 256, bb);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) th[j] = bb[j];
+    __builtin_amdgcn_sched_barrier(0);
+    dense_acc<16, 16, 1, float>(w, h2, th);
+    materialize<16>(th);
+  }
+}
+
+// out[i] = sum_j W[i][j] * in[j]  (data backprop through a layer y = x W)
+__device__ __forceinline__ void dense_T(uniform_ptr W, const float (&in)[16], float (&out)[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) {
+    float w0[16], w1[16];
+    load_row<16>(W + i * 16, w0);
+    load_row<16>(W + (i + 1) * 16, w1);
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { a0 = fmaf(w0[j], in[j], a0); a1 = fmaf(w1[j], in[j], a1); }
+    out[i] = a0; out[i + 1] = a1;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// dW[i][j] += sum over the wave's 64 samples of a_i * b_j, on the matrix core.
+// `stage` is this wave's LDS staging area (2 x 16 x STG floats).  Sample s goes
+// to MFMA step n = s & 15, k-slot g = s >> 4.  dW is row-major [rows][16] in
+// this wave's private gradient slab; only rows < n_rows are stored.  If db is
+// non-null the column sums of b are added to db[16].
+// ---------------------------------------------------------------------------
+constexpr int STG = 68;   // row stride of the staging tiles: conflict-free ds_read_b128
+
+__device__ __forceinline__ void wgrad_mfma(float* stage, const float (&a)[16], const float (&b)[16],
+                                           float* __restrict__ dW, int n_rows, float* __restrict__ db) {
+  const int lane = threadIdx.x & 63;
+  float* sa = stage;
+  float* sb = stage + 16 * STG;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { sa[i * STG + lane] = a[i]; sb[i * STG + lane] = b[i]; }
+  __builtin_amdgcn_wave_barrier();
+  const int g = lane >> 4, i = lane & 15;
+  f4 av[4], bv[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    av[n] = *reinterpret_cast<const f4*>(sa + i * STG + 16 * g + 4 * n);
+    bv[n] = *reinterpret_cast<const f4*>(sb + i * STG + 16 * g + 4 * n);
+  }
+  __builtin_amdgcn_wave_barrier();
+  f4 acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = (4 * g + r < n_rows) ? dW[(4 * g + r) * 16 + i] : 0.0f;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[n][e], bv[n][e], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) if (4 * g + r < n_rows) dW[(4 * g + r) * 16 + i] = acc[r];
+  if (db) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) sum += (bv[n][0] + bv[n][1]) + (bv[n][2] + bv[n][3]);
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (g == 0) db[i] += sum;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Conditioner backward (M = 2).  theta_bar -> weight gradients (into the
+// wave's slab `gw`, laid out like the flat parameters of this conditioner) and
+// adjoints of the d conditioning inputs (accumulated into adj_col).
+// Lanes whose sample is beyond the batch must pass theta_bar = 0.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void conditioner_bwd(uniform_ptr w, int d, float c, const float* col, int first_idx,
+                                                int idx_step, int stride, const float (&h1)[16],
+                                                const float (&h2)[16], const float (&tb)[16], float* adj_col,
+                                                float* __restrict__ gw, float* stage) {
+  w = launder(w);
+  const int o_b0 = (1 + d) * 16, o_w1 = o_b0 + 16, o_b1 = o_w1 + 256, o_wo = o_b1 + 16, o_bo = o_wo + 256;
+  // output layer
+  wgrad_mfma(stage, h2, tb, gw + o_wo, 16, gw + o_bo);
+  float g2[16];
+  dense_T(w + o_wo, tb, g2);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) g2[i] = h2[i] > 0.0f ? g2[i] : 0.0f;
+  materialize<16>(g2);
+  // hidden layer
+  wgrad_mfma(stage, h1, g2, gw + o_w1, 16, gw + o_b1);
+  float g1[16];
+  dense_T(w + o_w1, g2, g1);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) g1[i] = h1[i] > 0.0f ? g1[i] : 0.0f;
+  materialize<16>(g1);
+  // first layer: inputs [c, v_0..v_{d-1}, 1] (the constant row yields the bias gradient)
+  float in[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) in[r] = 0.0f;
+  in[0] = c;
+  for (int q = 0; q < d && q < 14; ++q) {
+    const float v = col[(first_idx + q * idx_step) * stride];
+#pragma unroll
+    for (int r = 1; r < 15; ++r) in[r] = (r == q + 1) ? v : in[r];
+  }
+#pragma unroll
+  for (int r = 1; r < 16; ++r) in[r] = (r == d + 1) ? 1.0f : in[r];
+  wgrad_mfma(stage, in, g1, gw, d + 2, nullptr);
+  for (int q = 0; q < d; ++q) {          // adjoints of the conditioning inputs
+    float wr[16];
+    load_row<16>(w + (1 + q) * 16, wr);
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc = fmaf(wr[j], g1[j], acc);
+    adj_col[(first_idx + q * idx_step) * stride] += acc;
+  }
+}
+
+}  // namespace cnf

@@ -1,0 +1,82 @@
+// cnf_common.h -- structs shared by the translation units of libcnf_ot_amd.so
+// (cnf_flow.hip: forward kernels + C ABI; cnf_grad.hip: backward + Adam).
+#pragma once
+
+#include "cnf_device.h"
+#include "../../include/cnf_ot_amd.h"
+
+namespace cnf {
+
+constexpr int TILE = 256;
+constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
+
+struct ModelArgs {
+  const float* prep;     // prepared model buffer
+  const float* wq;       // MFMA-layout weights (inside prep), or null
+  int64_t per_layer;     // floats of conditioner weights per flow layer
+  int64_t per_layer_q;   // floats of MFMA-layout weights per flow layer
+  int32_t D, L, M;
+  SplineConsts sc;
+};
+
+// target drift of flow_matching_loss_fn at r (this thread's column `r3`), dim i
+template <class T>
+__device__ __forceinline__ T drift_of(const float* r3, int i, int D, int TS, int subtype, float a) {
+  const T ri = lds_get<T>(r3, i, TS);
+  switch (subtype) {
+    case CNF_DRIFT_SMILE: {          // applications.py:353-357 (2-D)
+      const T x = lds_get<T>(r3, 0, TS), y = lds_get<T>(r3, 1, TS);
+      const T q = x * x + y * y - 4.0f;
+      return (i == 0 ? -q * x : -q * y - (y - 1.0f) * 2.0f) * a;
+    }
+    case CNF_DRIFT_NONGRADIENT: {    // applications.py:358-363: -a r + 0.5 (r @ J), J=[[0,1],[-1,0]]
+      const T x = lds_get<T>(r3, 0, TS), y = lds_get<T>(r3, 1, TS);
+      return i == 0 ? x * -a - y * 0.5f : y * -a + x * 0.5f;
+    }
+    case CNF_DRIFT_LORENZ: {         // applications.py:364-372, _r = 9
+      const T x = lds_get<T>(r3, 0, TS), y = lds_get<T>(r3, 1, TS), z = lds_get<T>(r3, 2, TS);
+      if (i == 0) return (y - x) * 10.0f;
+      if (i == 1) return x * 9.0f * (splat<T>(28.0f / 9.0f) - z) - y;
+      return x * 9.0f * y - z * (8.0f / 3.0f);
+    }
+    default: return ri * -a;         // OU drift, applications.py:310
+  }
+}
+
+}  // namespace cnf
+
+struct CnfModel {
+  // (opaque to callers; see include/cnf_ot_amd.h)
+  CnfConfig cfg;
+  cnf::SplineConsts sc;
+  float* prep;            // device
+  int64_t n_params;
+  int64_t per_layer;
+  int device;
+  int num_cus;
+  int fast_math;          // 1: hardware transcendentals (default), 0: ocml
+  int force_spl;          // 0: automatic; 1 / 2: samples per lane (tests, bench)
+  int use_mfma;           // 1: MFMA conditioner where available (H = 16, K = 5, fast math)
+  uint32_t div_magic;     // ceil(2^32 / D)
+  int64_t per_layer_q;    // MFMA-layout floats per flow layer (0: not available)
+  int64_t mfma_off;       // offset of the MFMA-layout weights inside prep (floats)
+  int params_set;
+  float* grad_slabs;      // per-wave gradient slabs (cnf_grad_enable), or null
+  int64_t grad_max_blocks;
+};
+
+#ifdef CNF_MINIMAL_CONFIGS   /* faster builds while iterating on the kernels */
+#define CNF_KERNEL_CONFIGS(X) X(16, 5)
+#else
+#define CNF_KERNEL_CONFIGS(X) \
+  X(8, 5) X(16, 4) X(16, 5) X(16, 8) X(16, 10) X(32, 5) X(32, 8) X(64, 5)
+#endif
+
+static inline cnf::ModelArgs model_args(const CnfModel* m) {
+  cnf::ModelArgs a;
+  a.prep = m->prep; a.per_layer = m->per_layer;
+  a.wq = m->mfma_off > 0 ? m->prep + m->mfma_off : nullptr; a.per_layer_q = m->per_layer_q;
+  a.D = m->cfg.dim; a.L = m->cfg.num_layers; a.M = m->cfg.mlp_num_layers;
+  a.sc = m->sc;
+  return a;
+}

@@ -14,8 +14,7 @@
 //  * the shared `first` spline is pre-normalised (float64, once per parameter
 //    set) into a 12-float-per-bin table that is staged in LDS and gathered by
 //    per-lane bin index.
-#include "cnf_device.h"
-#include "../../include/cnf_ot_amd.h"
+#include "cnf_common.h"
 
 #include <math.h>
 #include <new>
@@ -24,20 +23,10 @@
 
 namespace cnf {
 
-constexpr int TILE = 256;
-constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
 
 enum CMode { C_SINGLE = 0, C_PER_SAMPLE = 1, C_TILE_UNIFORM = 2, C_GENERIC = 3 };
 enum AuxMode { AUX_LOGDET = 0, AUX_LOGPROB = 1 };
 
-struct ModelArgs {
-  const float* prep;     // prepared model buffer
-  const float* wq;       // MFMA-layout weights (inside prep), or null
-  int64_t per_layer;     // floats of conditioner weights per flow layer
-  int64_t per_layer_q;   // floats of MFMA-layout weights per flow layer
-  int32_t D, L, M;
-  SplineConsts sc;
-};
 
 struct FlowArgs {
   ModelArgs m;
@@ -315,30 +304,6 @@ __device__ __forceinline__ void copy_cols(float* dst, const float* src, int D, i
   for (int d = 0; d < D; ++d) lds_put(dst, d, TS, lds_get<T>(src, d, TS));
 }
 
-// target drift of flow_matching_loss_fn at r (this thread's column `r3`), dim i
-template <class T>
-__device__ __forceinline__ T drift_of(const float* r3, int i, int D, int TS, int subtype, float a) {
-  const T ri = lds_get<T>(r3, i, TS);
-  switch (subtype) {
-    case CNF_DRIFT_SMILE: {          // applications.py:353-357 (2-D)
-      const T x = lds_get<T>(r3, 0, TS), y = lds_get<T>(r3, 1, TS);
-      const T q = x * x + y * y - 4.0f;
-      return (i == 0 ? -q * x : -q * y - (y - 1.0f) * 2.0f) * a;
-    }
-    case CNF_DRIFT_NONGRADIENT: {    // applications.py:358-363: -a r + 0.5 (r @ J), J=[[0,1],[-1,0]]
-      const T x = lds_get<T>(r3, 0, TS), y = lds_get<T>(r3, 1, TS);
-      return i == 0 ? x * -a - y * 0.5f : y * -a + x * 0.5f;
-    }
-    case CNF_DRIFT_LORENZ: {         // applications.py:364-372, _r = 9
-      const T x = lds_get<T>(r3, 0, TS), y = lds_get<T>(r3, 1, TS), z = lds_get<T>(r3, 2, TS);
-      if (i == 0) return (y - x) * 10.0f;
-      if (i == 1) return x * 9.0f * (splat<T>(28.0f / 9.0f) - z) - y;
-      return x * 9.0f * y - z * (8.0f / 3.0f);
-    }
-    default: return ri * -a;         // OU drift, applications.py:310
-  }
-}
-
 template <bool FAST, class T>
 __device__ __forceinline__ T potential_of(const float* y, int D, int TS, int subtype, float a) {
   using M = Math<FAST>;
@@ -503,29 +468,7 @@ __global__ void fill_normal_kernel(uint64_t seed, uint64_t first_element, int64_
 // ===========================================================================
 using namespace cnf;
 
-struct CnfModel {
-  CnfConfig cfg;
-  SplineConsts sc;
-  float* prep;            // device
-  int64_t n_params;
-  int64_t per_layer;
-  int device;
-  int num_cus;
-  int fast_math;          // 1: hardware transcendentals (default), 0: ocml
-  int force_spl;          // 0: automatic; 1 / 2: samples per lane (tests, bench)
-  int use_mfma;           // 1: MFMA conditioner where available (H = 16, K = 5, fast math)
-  uint32_t div_magic;     // ceil(2^32 / D)
-  int64_t per_layer_q;    // MFMA-layout floats per flow layer (0: not available)
-  int64_t mfma_off;       // offset of the MFMA-layout weights inside prep (floats)
-  int params_set;
-};
 
-#ifdef CNF_MINIMAL_CONFIGS   /* faster builds while iterating on the kernels */
-#define CNF_KERNEL_CONFIGS(X) X(16, 5)
-#else
-#define CNF_KERNEL_CONFIGS(X) \
-  X(8, 5) X(16, 4) X(16, 5) X(16, 8) X(16, 10) X(32, 5) X(32, 8) X(64, 5)
-#endif
 
 static int config_valid(const CnfConfig* c) {
   if (!c) return 0;
@@ -619,6 +562,7 @@ extern "C" int cnf_model_create(const CnfConfig* cfg, CnfModel** out) {
 extern "C" void cnf_model_destroy(CnfModel* m) {
   if (!m) return;
   if (m->prep) (void)hipFree(m->prep);
+  if (m->grad_slabs) (void)hipFree(m->grad_slabs);
   delete m;
 }
 
@@ -660,14 +604,6 @@ extern "C" int cnf_model_set_params(CnfModel* m, const float* params, void* stre
   return CNF_OK;
 }
 
-static ModelArgs model_args(const CnfModel* m) {
-  ModelArgs a;
-  a.prep = m->prep; a.per_layer = m->per_layer;
-  a.wq = m->mfma_off > 0 ? m->prep + m->mfma_off : nullptr; a.per_layer_q = m->per_layer_q;
-  a.D = m->cfg.dim; a.L = m->cfg.num_layers; a.M = m->cfg.mlp_num_layers;
-  a.sc = m->sc;
-  return a;
-}
 
 // Two samples per lane (packed fp32) once the batch fills every SIMD with at
 // least one wave of sample pairs; one sample per lane below that.

@@ -1,0 +1,452 @@
+// cnf_grad.hip -- backward pass of the fused Monte-Carlo loss terms and the
+// Adam update: the MI355X replacement of `jax.value_and_grad(loss_fn)` +
+// `optax.adam` in cnf_ot/mfc/solvers.py:90-97.
+//
+// One launch = one loss term over (time-slice, sample tile), like loss_kernel,
+// but it also back-propagates the term through every flow pass it made:
+//   * each pass is re-run with its layer inputs stashed in LDS (recompute
+//     instead of storing activations), then differentiated layer by layer in
+//     reverse: spline partials (cnf_backward.h) -> conditioner backward;
+//   * data backprop through the 16x16 layers uses scalar (SGPR) weights;
+//   * weight gradients are batch GEMMs on the matrix cores
+//     (v_mfma_f32_16x16x4_f32), accumulated straight into a per-wave gradient
+//     slab in global memory (plain read-modify-write: a slab has one owner, so
+//     the result is deterministic); grad_finish_kernel sums the slabs.
+// Built for the reference's network only: hidden 16, 2 hidden layers, 5 bins.
+#include "cnf_backward.h"
+
+#include <math.h>
+
+namespace cnf {
+
+constexpr int GK = 5;              // bins
+constexpr int GP = 3 * GK + 1;     // 16 spline parameters
+constexpr int GTS = TILE;          // one sample per lane
+
+struct GradArgs {
+  ModelArgs m;
+  CnfLossSpec spec;
+  const float* pts;
+  const float* t;
+  double* sums;          // [n_slices] loss-term sums (value of value_and_grad)
+  float* slabs;          // [gridDim.x * 4][n_params]
+  int64_t n_params;
+  int64_t B, n_slices, pts_slice_stride;
+  float scale;           // d(total loss) / d(this term's sum)
+  uint32_t div_magic;
+};
+
+struct FirstAcc { float Wb[GK], Hb[GK], Db[GK + 1]; };
+
+__device__ __forceinline__ void tile_load1(const float* __restrict__ g, float* U, int D, uint32_t magic,
+                                           int64_t tile_start, int64_t B) {
+  const int64_t base = tile_start * D;
+  const int n_el = (int)(B - tile_start < GTS ? B - tile_start : GTS) * D;
+  for (int e = threadIdx.x; e < GTS * D; e += TILE) {
+    const int s = magic ? (int)__umulhi((uint32_t)e, magic) : e, d = e - s * D;
+    U[d * GTS + s] = e < n_el ? g[base + e] : 0.0f;
+  }
+}
+
+__device__ __forceinline__ int64_t cond_prefix(int d) {      // floats of conditioners 1..d-1 (H=16, M=2, P=16)
+  int64_t o = 0;
+  for (int dd = 1; dd < d; ++dd) o += cond_floats(dd, 16, 2, 16);
+  return o;
+}
+
+// forward of one pass with every layer input kept: St[s] is the input of step s
+// (St[0] filled by the caller), St[L] the result.  Returns the log-det sum.
+template <bool TO_BASE, bool FAST>
+__device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, const float* tab, float* St, float c) {
+  constexpr bool INV = !TO_BASE;
+  const int D = a.D;
+  uniform_ptr weights = as_uniform(a.prep + hdr_floats(GK));
+  float acc = 0.0f;
+  for (int s = 0; s < a.L; ++s) {
+    const int l = TO_BASE ? a.L - 1 - s : s;
+    const bool odd = l & 1;
+    const int first_idx = odd ? D - 1 : 0, idx_step = odd ? -1 : 1;
+    const float* cu = St + s * D * GTS + threadIdx.x;
+    float* co = St + (s + 1) * D * GTS + threadIdx.x;
+    float o, ld;
+    table_spline<GK, INV, FAST, float>(tab, cu[first_idx * GTS], a.sc, o, ld);
+    co[first_idx * GTS] = o;
+    acc += ld;
+    uniform_ptr w = weights + l * a.per_layer;
+    for (int d = 1; d < D; ++d) {
+      const int i = first_idx + d * idx_step;
+      float th[GP];
+      conditioner<16, GP, float>(w, d, 2, c, TO_BASE ? co : cu, first_idx, idx_step, GTS, th);
+      cond_spline<GK, INV, FAST, float>(th, cu[i * GTS], a.sc, o, ld);
+      co[i * GTS] = o;
+      acc += ld;
+      w += cond_floats(d, 16, 2, GP);
+    }
+  }
+  return acc;
+}
+
+// backward of the pass whose stash is in St.  Aa holds the adjoint of the final
+// output on entry and the adjoint of the pass input on exit (the function
+// ping-pongs between Aa and Ab and returns the buffer that holds the result).
+template <bool TO_BASE, bool FAST>
+__device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab, const float* St, float* Aa,
+                                           float* Ab, float ld_bar, float c, float* gslab, float* stage,
+                                           FirstAcc& fa) {
+  constexpr bool INV = !TO_BASE;
+  const int D = a.D;
+  uniform_ptr weights = as_uniform(a.prep + hdr_floats(GK));
+  float* Ao = Aa;
+  float* Au = Ab;
+  for (int s = a.L - 1; s >= 0; --s) {
+    const int l = TO_BASE ? a.L - 1 - s : s;
+    const bool odd = l & 1;
+    const int first_idx = odd ? D - 1 : 0, idx_step = odd ? -1 : 1;
+    const float* cu = St + s * D * GTS + threadIdx.x;
+    const float* co = St + (s + 1) * D * GTS + threadIdx.x;
+    float* ao = Ao + threadIdx.x;
+    float* au = Au + threadIdx.x;
+    for (int d = 0; d < D; ++d) au[d * GTS] = 0.0f;
+    int64_t off = cond_prefix(D);                     // end of this layer's conditioners
+    for (int d = D - 1; d >= 1; --d) {
+      off -= cond_floats(d, 16, 2, GP);
+      const int i = first_idx + d * idx_step;
+      uniform_ptr w = weights + l * a.per_layer + off;
+      float h1[16], h2[16], th[GP], tb[GP];
+      conditioner_keep(w, d, c, TO_BASE ? co : cu, first_idx, idx_step, GTS, h1, h2, th);
+      const float vb = cond_spline_bwd<GK, INV, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
+      au[i * GTS] += vb;
+      conditioner_bwd(w, d, c, TO_BASE ? co : cu, first_idx, idx_step, GTS, h1, h2, tb, TO_BASE ? ao : au,
+                      gslab + GP + l * a.per_layer + off, stage);
+    }
+    au[first_idx * GTS] += table_spline_bwd<GK, INV>(tab, cu[first_idx * GTS], co[first_idx * GTS],
+                                                      ao[first_idx * GTS], ld_bar, a.sc, fa.Wb, fa.Hb, fa.Db);
+    float* t = Ao; Ao = Au; Au = t;
+  }
+  return Ao;
+}
+
+__device__ __forceinline__ float base_lp(const float* col, int D) {
+  float b = 0.0f;
+  for (int d = 0; d < D; ++d) { const float x = col[d * GTS]; b = fmaf(-0.5f * x, x, b); }
+  return b - D * HALF_LOG_2PI;
+}
+
+// R3b[e] -= sum_d ubar_d * d drift_d / d r_e   (flow_matching_loss_fn's target field)
+__device__ __forceinline__ void drift_vjp(const float* r3, const float* ub, float* r3b, int D, int subtype, float a) {
+  switch (subtype) {
+    case CNF_DRIFT_SMILE: {
+      const float x = r3[0], y = r3[GTS], q = x * x + y * y - 4.0f, u0 = ub[0], u1 = ub[GTS];
+      r3b[0] -= u0 * (-a * (q + 2.0f * x * x)) + u1 * (-a * 2.0f * x * y);
+      r3b[GTS] -= u0 * (-a * 2.0f * x * y) + u1 * (-a * (q + 2.0f * y * y + 2.0f));
+      break;
+    }
+    case CNF_DRIFT_NONGRADIENT: {
+      const float u0 = ub[0], u1 = ub[GTS];
+      r3b[0] -= u0 * (-a) + u1 * 0.5f;
+      r3b[GTS] -= u0 * (-0.5f) + u1 * (-a);
+      break;
+    }
+    case CNF_DRIFT_LORENZ: {
+      const float x = r3[0], y = r3[GTS], z = r3[2 * GTS], u0 = ub[0], u1 = ub[GTS], u2 = ub[2 * GTS];
+      r3b[0] -= u0 * -10.0f + u1 * (28.0f - 9.0f * z) + u2 * 9.0f * y;
+      r3b[GTS] -= u0 * 10.0f - u1 + u2 * 9.0f * x;
+      r3b[2 * GTS] -= u1 * (-9.0f * x) + u2 * (-8.0f / 3.0f);
+      break;
+    }
+    default:
+      for (int d = 0; d < D; ++d) r3b[d * GTS] += a * ub[d * GTS];
+  }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(TILE, 1) void grad_kernel(const GradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int HDR = hdr_floats(GK);
+  const int D = a.m.D, L = a.m.L;
+  const int DT = D * GTS;
+  float* tab = lds;
+  float* Nn = lds + HDR;
+  float* St = Nn + DT;                  // (L+1) stashes
+  float* Aa = St + (L + 1) * DT;
+  float* Ab = Aa + DT;
+  float* V = Ab + DT;
+  float* R3 = V + DT;
+  float* R3b = R3 + DT;
+  float* Ub = R3b + DT;
+  float* stage = Ub + DT + (threadIdx.x >> 6) * (2 * 16 * STG);
+  for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = a.m.prep[i];
+  const int tid = threadIdx.x;
+  const int kind = a.spec.kind;
+  float* gslab = a.slabs + ((int64_t)blockIdx.x * 4 + (tid >> 6)) * a.n_params;
+  FirstAcc fa;
+#pragma unroll
+  for (int j = 0; j < GK; ++j) { fa.Wb[j] = 0.0f; fa.Hb[j] = 0.0f; }
+#pragma unroll
+  for (int j = 0; j <= GK; ++j) fa.Db[j] = 0.0f;
+
+  const int64_t tiles_per_slice = (a.B + GTS - 1) / GTS;
+  const int64_t n_tiles = tiles_per_slice * a.n_slices;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t slice = tile / tiles_per_slice;
+    const int64_t tile_start = (tile - slice * tiles_per_slice) * GTS;
+    const bool valid = tile_start + tid < a.B;
+    const float sc = valid ? a.scale : 0.0f;
+    __syncthreads();
+    tile_load1(a.pts + slice * a.pts_slice_stride * D, Nn, D, a.div_magic, tile_start, a.B);
+    const float t = a.t[slice];
+    __syncthreads();
+    float* n_ = Nn + tid;
+    float* s0 = St + tid;               // stash 0 column
+    float* sL = St + L * DT + tid;      // final output column
+    float* aa = Aa + tid;
+    float lossv = 0.0f;
+
+    if (kind == CNF_TERM_NEG_LOGPROB) {
+      for (int d = 0; d < D; ++d) s0[d * GTS] = n_[d * GTS];
+      const float ildj = pass_fwd_stash<true, FAST>(a.m, tab, St, t);
+      lossv = -(base_lp(sL, D) + ildj);
+      for (int d = 0; d < D; ++d) aa[d * GTS] = sc * sL[d * GTS];      // d(-lp)/dx_d = x_d
+      pass_bwd<true, FAST>(a.m, tab, St, Aa, Ab, -sc, t, gslab, stage, fa);
+    } else if (kind == CNF_TERM_POTENTIAL || kind == CNF_TERM_REVERSE_KL) {
+      for (int d = 0; d < D; ++d) s0[d * GTS] = n_[d * GTS];
+      const float fldj = pass_fwd_stash<false, FAST>(a.m, tab, St, t);
+      float ld_bar = 0.0f;
+      if (kind == CNF_TERM_POTENTIAL) {
+        const float pa = a.spec.a;
+        if (a.spec.subtype == CNF_POT_DOUBLE_WELL) {
+          float sm = 0.0f, sp = 0.0f;
+          for (int d = 0; d < D; ++d) { const float r = sL[d * GTS]; sm = fmaf(r - pa, r - pa, sm); sp = fmaf(r + pa, r + pa, sp); }
+          lossv = sm * sp * 0.25f;
+          for (int d = 0; d < D; ++d) { const float r = sL[d * GTS]; aa[d * GTS] = sc * 0.5f * ((r - pa) * sp + (r + pa) * sm); }
+        } else {
+          float s2 = 0.0f;
+          for (int d = 0; d < D; ++d) { const float r = sL[d * GTS]; s2 = fmaf(r, r, s2); }
+          if (a.spec.subtype == CNF_POT_OBSTACLE) {
+            lossv = 50.0f * expf(-0.5f * s2);
+            for (int d = 0; d < D; ++d) aa[d * GTS] = -sc * lossv * sL[d * GTS];
+          } else {
+            lossv = 0.5f * s2;
+            for (int d = 0; d < D; ++d) aa[d * GTS] = sc * sL[d * GTS];
+          }
+        }
+      } else {
+        const float lp = base_lp(n_, D) - fldj;
+        float s2 = 0.0f;
+        for (int d = 0; d < D; ++d) { const float r = sL[d * GTS]; s2 = fmaf(r, r, s2); }
+        const float Tt = a.spec.T, vs = 2.0f / a.spec.beta * (Tt + 1.0f), vt = 2.0f / a.spec.beta;
+        const float ws = (Tt - t) / Tt, wt = t / Tt;
+        const float ls = -0.5f * D * logf(6.283185307179586f * vs), lt = -0.5f * D * logf(6.283185307179586f * vt);
+        const float as = -0.5f * s2 / vs + ls, at = -0.5f * s2 / vt + lt;
+        const float mx = fmaxf(as, at);
+        const float es = expf(as - mx) * ws, et = expf(at - mx) * wt;
+        lossv = lp - (mx + logf(es + et));
+        // d logmix / d y_d = -y_d (es/vs + et/vt) / (es + et)
+        const float g = (es / vs + et / vt) / (es + et);
+        for (int d = 0; d < D; ++d) aa[d * GTS] = sc * g * sL[d * GTS];
+        ld_bar = -sc;
+      }
+      pass_bwd<false, FAST>(a.m, tab, St, Aa, Ab, ld_bar, t, gslab, stage, fa);
+    } else {
+      const float dt = a.spec.dt, inv_dt = 1.0f / dt;
+      float* v_ = V + tid;
+      for (int d = 0; d < D; ++d) s0[d * GTS] = n_[d * GTS];
+      pass_fwd_stash<false, FAST>(a.m, tab, St, t - 0.5f * dt);
+      for (int d = 0; d < D; ++d) v_[d * GTS] = sL[d * GTS];
+      pass_fwd_stash<false, FAST>(a.m, tab, St, t + 0.5f * dt);          // stash now holds the r2 pass
+      for (int d = 0; d < D; ++d) v_[d * GTS] = (sL[d * GTS] - v_[d * GTS]) * inv_dt;
+      float* ub = Ub + tid;
+      if (kind == CNF_TERM_KINETIC) {
+        for (int d = 0; d < D; ++d) { const float v = v_[d * GTS]; lossv = fmaf(v, v, lossv); ub[d * GTS] = 2.0f * sc * v; }
+      } else {
+        const float dx = a.spec.dx, coef = a.spec.coef;
+        float* r3 = R3 + tid;
+        float* r3b = R3b + tid;
+        pass_fwd_stash<false, FAST>(a.m, tab, St, t);
+        for (int d = 0; d < D; ++d) { r3[d * GTS] = sL[d * GTS]; r3b[d * GTS] = 0.0f; }
+        for (int d = 0; d < D; ++d) {
+          float lp[2];
+          for (int sg = 0; sg < 2; ++sg) {                               // + then -: the stash ends on the - pass
+            for (int e = 0; e < D; ++e) s0[e * GTS] = r3[e * GTS];
+            s0[d * GTS] += sg == 0 ? 0.5f * dx : -0.5f * dx;
+            const float ildj = pass_fwd_stash<true, FAST>(a.m, tab, St, t);
+            lp[sg] = base_lp(sL, D) + ildj;
+          }
+          float u = fmaf((lp[0] - lp[1]) / dx, coef, v_[d * GTS]);
+          if (kind == CNF_TERM_FLOW_MATCHING) u -= drift_of<float>(r3, d, D, GTS, a.spec.subtype, a.spec.a);
+          lossv = fmaf(u, u, lossv);
+          const float ubar = 2.0f * sc * u;
+          ub[d * GTS] = ubar;
+          for (int sg = 1; sg >= 0; --sg) {                              // - first (its stash is live), then +
+            const float lp_bar = (sg == 0 ? ubar : -ubar) * coef / dx;
+            if (sg == 0) {
+              for (int e = 0; e < D; ++e) s0[e * GTS] = r3[e * GTS];
+              s0[d * GTS] += 0.5f * dx;
+              pass_fwd_stash<true, FAST>(a.m, tab, St, t);
+            }
+            for (int e = 0; e < D; ++e) aa[e * GTS] = -lp_bar * sL[e * GTS];   // d base / d x_e = -x_e
+            const float* ain = pass_bwd<true, FAST>(a.m, tab, St, Aa, Ab, lp_bar, t, gslab, stage, fa) + tid;
+            for (int e = 0; e < D; ++e) r3b[e * GTS] += ain[e * GTS];
+          }
+        }
+        if (kind == CNF_TERM_FLOW_MATCHING) drift_vjp(r3, ub, r3b, D, a.spec.subtype, a.spec.a);
+        // r3 pass
+        for (int d = 0; d < D; ++d) s0[d * GTS] = n_[d * GTS];
+        pass_fwd_stash<false, FAST>(a.m, tab, St, t);
+        for (int d = 0; d < D; ++d) aa[d * GTS] = r3b[d * GTS];
+        pass_bwd<false, FAST>(a.m, tab, St, Aa, Ab, 0.0f, t, gslab, stage, fa);
+        // r2 pass (re-run: its stash was overwritten)
+        for (int d = 0; d < D; ++d) s0[d * GTS] = n_[d * GTS];
+        pass_fwd_stash<false, FAST>(a.m, tab, St, t + 0.5f * dt);
+      }
+      for (int d = 0; d < D; ++d) aa[d * GTS] = ub[d * GTS] * inv_dt;
+      pass_bwd<false, FAST>(a.m, tab, St, Aa, Ab, 0.0f, t + 0.5f * dt, gslab, stage, fa);
+      for (int d = 0; d < D; ++d) s0[d * GTS] = n_[d * GTS];
+      pass_fwd_stash<false, FAST>(a.m, tab, St, t - 0.5f * dt);
+      for (int d = 0; d < D; ++d) aa[d * GTS] = -ub[d * GTS] * inv_dt;
+      pass_bwd<false, FAST>(a.m, tab, St, Aa, Ab, 0.0f, t - 0.5f * dt, gslab, stage, fa);
+    }
+    float part = valid ? lossv : 0.0f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if ((tid & 63) == 0) atomicAdd(a.sums + slice, (double)part);
+  }
+  // per-bin adjoint sums of the shared `first` spline: wave reduce, one owner write
+  float red[GP];
+#pragma unroll
+  for (int j = 0; j < GK; ++j) { red[j] = fa.Wb[j]; red[GK + j] = fa.Hb[j]; }
+#pragma unroll
+  for (int j = 0; j <= GK; ++j) red[2 * GK + j] = fa.Db[j];
+#pragma unroll
+  for (int j = 0; j < GP; ++j) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) red[j] += __shfl_xor(red[j], off, 64);
+  }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int j = 0; j < GP; ++j) gslab[j] += red[j];
+  }
+}
+
+// grad[p] += sum over slabs; the first 16 entries are per-bin adjoint sums of
+// the `first` spline and go through the softmax / softplus Jacobians (float64).
+__global__ void grad_finish_kernel(const float* __restrict__ slabs, int64_t n_slabs, int64_t n_params,
+                                   const float* __restrict__ params, float* __restrict__ grad, double span_eff,
+                                   double sp_offset) {
+  __shared__ double raw[GP];
+  const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < GP) {
+    double s = 0.0;
+    for (int64_t b = 0; b < n_slabs; ++b) s += (double)slabs[b * n_params + threadIdx.x];
+    raw[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < GP) {
+    const int j = threadIdx.x;
+    double g;
+    if (j < 2 * GK) {
+      const int part = j / GK, jj = j % GK;
+      double mx = params[part * GK];
+      for (int k = 1; k < GK; ++k) mx = fmax(mx, (double)params[part * GK + k]);
+      double pr[GK], sum = 0.0, dot = 0.0;
+      for (int k = 0; k < GK; ++k) { pr[k] = exp((double)params[part * GK + k] - mx); sum += pr[k]; }
+      for (int k = 0; k < GK; ++k) { pr[k] /= sum; dot += raw[part * GK + k] * pr[k]; }
+      g = span_eff * pr[jj] * (raw[j] - dot);
+    } else {
+      g = raw[j] / (1.0 + exp(-((double)params[j] + sp_offset)));
+    }
+    grad[j] += (float)g;
+  } else if (p >= GP && p < n_params) {
+    float s = 0.0f;
+    for (int64_t b = 0; b < n_slabs; ++b) s += slabs[b * n_params + p];
+    grad[p] += s;
+  }
+}
+
+// optax.adam(lr): mu = b1 mu + (1-b1) g; nu = b2 nu + (1-b2) g^2;
+// update = -lr * (mu / (1-b1^t)) / (sqrt(nu / (1-b2^t)) + eps)   (eps_root = 0)
+__global__ void adam_kernel(float* __restrict__ params, const float* __restrict__ grad, float* __restrict__ mu,
+                            float* __restrict__ nu, int64_t n, float lr, float b1, float b2, float eps,
+                            float bc1, float bc2) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = grad[i];
+  const float m = b1 * mu[i] + (1.0f - b1) * g;
+  const float v = b2 * nu[i] + (1.0f - b2) * g * g;
+  mu[i] = m; nu[i] = v;
+  params[i] -= lr * (m / bc1) / (sqrtf(v / bc2) + eps);
+}
+
+}  // namespace cnf
+
+using namespace cnf;
+
+extern "C" int cnf_grad_supported(const CnfConfig* c) {
+  return c && c->hidden_size == 16 && c->mlp_num_layers == 2 && c->num_bins == 5 && c->dim >= 1 && c->dim <= 15;
+}
+
+extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const float* pts, int pts_shared,
+                                   const float* t, int64_t n_slices, int64_t B, float scale, double* sums,
+                                   float* grad, const float* params, void* stream_) {
+  if (!m || !spec || !pts || !t || !sums || !grad || !params || n_slices < 0 || B < 0) return CNF_ERR_INVALID;
+  if (!m->params_set) return CNF_ERR_INVALID;
+  if (!cnf_grad_supported(&m->cfg)) return CNF_ERR_UNSUPPORTED;
+  if (spec->kind < CNF_TERM_KINETIC || spec->kind > CNF_TERM_NEG_LOGPROB) return CNF_ERR_INVALID;
+  const int D = m->cfg.dim, L = m->cfg.num_layers;
+  if (spec->kind <= CNF_TERM_FLOW_MATCHING && !(spec->dt > 0.f)) return CNF_ERR_INVALID;
+  if ((spec->kind == CNF_TERM_KINETIC_SCORE || spec->kind == CNF_TERM_FLOW_MATCHING) && !(spec->dx > 0.f)) return CNF_ERR_INVALID;
+  if (spec->kind == CNF_TERM_FLOW_MATCHING) {
+    if ((spec->subtype == CNF_DRIFT_SMILE || spec->subtype == CNF_DRIFT_NONGRADIENT) && D != 2) return CNF_ERR_INVALID;
+    if (spec->subtype == CNF_DRIFT_LORENZ && D != 3) return CNF_ERR_INVALID;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_slices == 0) return CNF_OK;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * (size_t)n_slices, stream) != hipSuccess) return CNF_ERR_HIP;
+  if (B == 0) return CNF_OK;
+  if (!m->grad_slabs) return CNF_ERR_INVALID;      // cnf_grad_enable first
+
+  GradArgs a;
+  a.m = model_args(m); a.spec = *spec; a.pts = pts; a.t = t; a.sums = sums;
+  a.slabs = m->grad_slabs; a.n_params = m->n_params;
+  a.B = B; a.n_slices = n_slices; a.pts_slice_stride = pts_shared ? 0 : B;
+  a.scale = scale; a.div_magic = m->div_magic;
+  int64_t grid = ((B + GTS - 1) / GTS) * n_slices;
+  if (grid > m->grad_max_blocks) grid = m->grad_max_blocks;
+  const size_t lds = (size_t)(hdr_floats(GK) + D * GTS * (1 + (L + 1) + 6) + 4 * 2 * 16 * STG) * sizeof(float);
+  if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
+  const int64_t n_slabs = grid * 4;
+  if (hipMemsetAsync(m->grad_slabs, 0, sizeof(float) * (size_t)(n_slabs * m->n_params), stream) != hipSuccess) return CNF_ERR_HIP;
+  if (m->fast_math) {
+    if (hipFuncSetAttribute((const void*)grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CNF_ERR_HIP;
+    hipLaunchKernelGGL(grad_kernel<true>, dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+  } else {
+    if (hipFuncSetAttribute((const void*)grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CNF_ERR_HIP;
+    hipLaunchKernelGGL(grad_kernel<false>, dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+  }
+  if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
+  const int fb = (int)((m->n_params + 255) / 256);
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(256), 0, stream, m->grad_slabs, n_slabs, m->n_params, params,
+                     grad, (double)m->sc.span_eff, (double)m->sc.sp_offset);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+extern "C" int cnf_grad_enable(CnfModel* m, int64_t max_blocks) {
+  if (!m) return CNF_ERR_INVALID;
+  if (!cnf_grad_supported(&m->cfg)) return CNF_ERR_UNSUPPORTED;
+  if (max_blocks <= 0) max_blocks = (int64_t)m->num_cus * 2;
+  if (m->grad_slabs && m->grad_max_blocks >= max_blocks) return CNF_OK;
+  if (m->grad_slabs) { (void)hipFree(m->grad_slabs); m->grad_slabs = nullptr; }
+  if (hipMalloc((void**)&m->grad_slabs, sizeof(float) * (size_t)(max_blocks * 4 * m->n_params)) != hipSuccess) return CNF_ERR_NOMEM;
+  m->grad_max_blocks = max_blocks;
+  return CNF_OK;
+}
+
+extern "C" int cnf_adam_step(float* params, const float* grad, float* mu, float* nu, int64_t n, float lr, float b1,
+                             float b2, float eps, int64_t step, void* stream) {
+  if (!params || !grad || !mu || !nu || n < 0 || step < 1) return CNF_ERR_INVALID;
+  if (n == 0) return CNF_OK;
+  const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grad,
+                     mu, nu, n, lr, b1, b2, eps, bc1, bc2);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}

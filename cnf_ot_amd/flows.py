@@ -204,6 +204,33 @@ class FlowEngine:
                                             sums.data_ptr(), _stream_ptr(self.device)), "cnf_loss_terms")
     return sums
 
+  def loss_terms_grad(self, spec, pts, t, B: int, shared: bool, scale: float, grad: torch.Tensor) -> torch.Tensor:
+    """cnf_loss_terms_grad: like `loss_terms`, and accumulates
+    scale * d(sum of the term)/d(params) into `grad` (flat float32 [n_params])."""
+    if self._flat is None:
+      raise RuntimeError("load(params) before asking for gradients")
+    if not getattr(self, "_grad_enabled", False):
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
+      self._grad_enabled = True
+    pts = self._points(pts, "loss_terms_grad")
+    if not torch.is_tensor(t):
+      t = torch.as_tensor(np.asarray(t, dtype=np.float32))
+    t = t.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+    n_slices = t.numel()
+    need = B if shared else n_slices * B
+    if pts.shape[0] != need:
+      raise ValueError(f"loss_terms_grad: pts has {pts.shape[0]} rows, expected {need}")
+    self._check_out(grad, (self.cfg.param_count(),), "grad")
+    sums = torch.empty(n_slices, dtype=torch.float64, device=self.device)
+    if n_slices > 0:
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_loss_terms_grad(self._h, _capi.ctypes.byref(spec), pts.data_ptr(),
+                                                 1 if shared else 0, t.data_ptr(), n_slices, B, float(scale),
+                                                 sums.data_ptr(), grad.data_ptr(), self._flat.data_ptr(),
+                                                 _stream_ptr(self.device)), "cnf_loss_terms_grad")
+    return sums
+
   def normal(self, seed, n_samples: int, first_sample: int = 0) -> torch.Tensor:
     """Base noise [n_samples, D]: Philox stream element (first_sample+i)*D+d."""
     seed, off = seed_to_u64(seed)

@@ -1,0 +1,132 @@
+"""Mirror of the training step of cnf_ot/mfc/solvers.py (the caller of the hot
+path): config keys of config/mfc.yaml, model construction (:41-56), the loss
+binding (:58-88), and `update` = value_and_grad + Adam (:90-97), on the HIP
+kernels.  Plotting / printing / post-training evaluation of the reference
+(:129-493) are out of scope; the two evaluators are
+in cnf_ot_amd.utils.
+"""
+from dataclasses import dataclass, field
+from functools import partial
+from typing import Any, Callable, Dict, Tuple
+
+import torch
+
+from . import _capi, applications
+from .flows import RQSFlow, FlowModel, _stream_ptr
+from .params import Params
+
+# config/mfc.yaml:6-40 (the checked-in defaults)
+DEFAULT_CONFIG: Dict[str, Dict[str, Any]] = {
+  "general": {"type": "rwpo", "dim": 2, "dx": 0.01, "dt": 0.01, "t_batch_size": 1, "seed": 42},
+  "ot": {"subtype": "free"},
+  "rwpo": {"T": 2, "beta": 10, "a": 1, "pot_type": "double_well"},
+  "fp": {"T": 1, "a": 1, "sigma": 0.5, "velocity_field_type": "gradient"},
+  "cnf": {"flow_num_layers": 2, "mlp_num_layers": 2, "hidden_size": 16, "num_bins": 5},
+  "train": {"epochs": 30000, "lr": 0.001, "_lambda": 5000.0, "batch_size": 2048, "eval_frequency": 100},
+}
+
+
+def load_config(path: str = None, overrides: Dict[str, Dict[str, Any]] = None) -> Dict[str, Dict[str, Any]]:
+  """yaml.safe_load(config/mfc.yaml) (solvers.py:496-500) merged over the
+  defaults; the unused `hydra:` block is ignored."""
+  cfg = {k: dict(v) for k, v in DEFAULT_CONFIG.items()}
+  if path is not None:
+    import yaml
+    with open(path) as f:
+      loaded = yaml.safe_load(f) or {}
+    for sec, vals in loaded.items():
+      if sec in cfg and isinstance(vals, dict):
+        cfg[sec].update(vals)
+  for sec, vals in (overrides or {}).items():
+    cfg.setdefault(sec, {}).update(vals)
+  return cfg
+
+
+def build_model(config) -> FlowModel:
+  """solvers.py:41-48"""
+  c = config["cnf"]
+  return RQSFlow(event_shape=(config["general"]["dim"],), num_layers=c["flow_num_layers"],
+                 hidden_sizes=[c["hidden_size"]] * c["mlp_num_layers"], num_bins=c["num_bins"], periodized=False)
+
+
+def bind_loss(config, model) -> Callable:
+  """solvers.py:58-88: loss_fn(params, rng, _lambda, batch_size)."""
+  g = config["general"]
+  _type, dim, dt, dx, tbs = g["type"], g["dim"], g["dt"], g["dx"], g["t_batch_size"]
+  if _type == "rwpo":
+    r = config["rwpo"]
+    return partial(applications.rwpo_loss_fn, model, dim, r["T"], r["beta"], dt, dx, tbs, r["pot_type"], r["a"])
+  if _type == "fp":
+    f = config["fp"]
+    return partial(applications.fp_loss_fn, model, dim, f["T"], f["a"], f["sigma"], dt, dx, tbs,
+                   f["velocity_field_type"])
+  if _type == "ot":
+    return partial(applications.ot_loss_fn, model, dim, 1, dt, tbs, config["ot"]["subtype"])
+  raise Exception(f"Unknown problem type: {_type}...")        # solvers.py:87-88
+
+
+@dataclass
+class AdamState:
+  """optax.adam state: step count and the two moment estimates (flat tensors)."""
+  step: int
+  mu: torch.Tensor
+  nu: torch.Tensor
+
+
+@dataclass
+class Adam:
+  """optax.adam(lr) (solvers.py:55): b1 = 0.9, b2 = 0.999, eps = 1e-8."""
+  lr: float
+  b1: float = 0.9
+  b2: float = 0.999
+  eps: float = 1e-8
+
+  def init(self, params: Params) -> AdamState:
+    return AdamState(0, torch.zeros_like(params.flat), torch.zeros_like(params.flat))
+
+  def apply(self, params: Params, grads: Params, state: AdamState) -> AdamState:
+    """optimizer.update + optax.apply_updates (solvers.py:95-96), in place on
+    params.flat (one kernel: cnf_adam_step)."""
+    lib = _capi.lib()
+    state.step += 1
+    dev = params.flat.device
+    with torch.cuda.device(dev):
+      _capi.check(lib.cnf_adam_step(params.flat.data_ptr(), grads.flat.data_ptr(), state.mu.data_ptr(),
+                                    state.nu.data_ptr(), params.flat.numel(), self.lr, self.b1, self.b2, self.eps,
+                                    state.step, _stream_ptr(dev)), "cnf_adam_step")
+    return state
+
+
+def make_update(loss_fn: Callable, optimizer: Adam, batch_size: int) -> Callable:
+  """`update` of solvers.py:90-97.  The reference returns new pytrees; here the
+  parameters and the optimiser state are updated IN PLACE (the same objects are
+  returned), which is what `params, opt_state = update(...)` callers expect."""
+  vg = applications.value_and_grad(loss_fn)
+
+  def update(params: Params, rng, _lambda, opt_state: AdamState) -> Tuple[torch.Tensor, Params, AdamState]:
+    loss, grads = vg(params, rng, _lambda, batch_size)
+    opt_state = optimizer.apply(params, grads, opt_state)
+    return loss, params, opt_state
+
+  return update
+
+
+def train(config, epochs: int = None, log=None):
+  """The training loop of solvers.py:99-127 without tqdm/plots: returns
+  (params, loss history as a list of 0-dim device tensors)."""
+  model = build_model(config)
+  seed = int(config["general"]["seed"])
+  params = model.init(seed)
+  opt = Adam(config["train"]["lr"])
+  state = opt.init(params)
+  update = make_update(bind_loss(config, model), opt, config["train"]["batch_size"])
+  n = config["train"]["epochs"] if epochs is None else epochs
+  hist = []
+  for step in range(n):
+    # update_rng, rng = jax.random.split(rng) (solvers.py:104): an independent Philox key per step
+    step_rng = (seed + 0x9E3779B97F4A7C15 * (step + 1)) & 0xFFFFFFFFFFFFFFFF
+    loss, params, state = update(params, step_rng, config["train"]["_lambda"], state)
+    hist.append(loss)
+    if log is not None and step % config["train"]["eval_frequency"] == 0:
+      log(step, float(loss))
+  return model, params, hist

@@ -174,6 +174,32 @@ int cnf_loss_terms(CnfModel *m, const CnfLossSpec *spec, const float *pts,
                    int pts_shared, const float *t, int64_t n_slices, int64_t B,
                    double *sums, void *stream);
 
+/* ---- value_and_grad + Adam (cnf_ot/mfc/solvers.py:90-97) -------------------
+ * Backward pass of the loss terms, for the reference's network (hidden 16, two
+ * hidden layers, 5 bins, dim <= 15): cnf_grad_supported() tells.
+ *
+ * cnf_grad_enable allocates the per-wave gradient slabs (the only allocation;
+ * call once, outside any graph capture; max_blocks <= 0: a default).
+ *
+ * cnf_loss_terms_grad = cnf_loss_terms (same arguments, same `sums`) PLUS
+ *   grad[p] += scale * d(sum over all slices and samples of the term)/d params[p]
+ * `grad` (device, cnf_param_count() floats) is ACCUMULATED into, so the caller
+ * zeroes it once and adds every term of a composite loss with its coefficient
+ * as `scale`.  `params` is the same flat vector that was given to
+ * cnf_model_set_params.  Results are deterministic (no float atomics). */
+int cnf_grad_supported(const CnfConfig *cfg);
+int cnf_grad_enable(CnfModel *m, int64_t max_blocks);
+int cnf_loss_terms_grad(CnfModel *m, const CnfLossSpec *spec, const float *pts,
+                        int pts_shared, const float *t, int64_t n_slices,
+                        int64_t B, float scale, double *sums, float *grad,
+                        const float *params, void *stream);
+
+/* optax.adam(lr) update in place (solvers.py:55,95-96): b1 = 0.9, b2 = 0.999,
+ * eps = 1e-8 are optax's defaults; `step` counts from 1. */
+int cnf_adam_step(float *params, const float *grad, float *mu, float *nu,
+                  int64_t n, float lr, float b1, float b2, float eps,
+                  int64_t step, void *stream);
+
 const char *cnf_strerror(int code);
 /* "gfx950" etc.: the offload arch this library was compiled for. */
 const char *cnf_build_arch(void);

@@ -1,0 +1,183 @@
+"""GPU parity of the backward pass (cnf_loss_terms_grad) and of the Adam update.
+
+Reference gradients: central finite differences (float64) of the oracle's
+restatement of each loss term over ALL parameters -- what
+`jax.value_and_grad(loss_fn)` of cnf_ot/mfc/solvers.py:94 differentiates.
+The losses are piecewise smooth in the parameters (ReLU, bin boundaries), and
+the finite-difference-in-time terms weight a sample whose ReLU switches between
+t - dt/2 and t + dt/2 by 1/dt, so a difference quotient that straddles such a
+kink is off by O(1): the reference is taken at h = 1e-7 and entries where
+h = 1e-6 disagrees are excluded (and counted) instead of being compared.
+
+Tolerance: |g_gpu - g_fd|_inf <= 5e-3 * |g_fd|_inf for the finite-difference
+terms (their per-sample velocities are fp32 differences divided by dt = 0.01,
+and the gradient is a difference of two such Jacobian products), 1e-3 for the
+direct terms.  Measured values are printed.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+  assert torch.cuda.is_available()
+  return torch.device("cuda", 0)
+
+
+def _fd_grad(fn, params64):
+  """(reference gradient at h = 1e-7, mask of entries where h = 1e-6 agrees)."""
+  out = []
+  for h in (1e-7, 1e-6):
+    g = np.zeros_like(params64)
+    for i in range(params64.size):
+      p = params64.copy(); p[i] += h
+      fp = fn(p)
+      p[i] -= 2 * h
+      g[i] = (fp - fn(p)) / (2 * h)
+    out.append(g)
+  scale = max(np.abs(out[0]).max(), 1e-30)
+  return out[0], np.abs(out[0] - out[1]) <= 1e-5 * scale
+
+
+def _run(dev, D, kind_spec, B, n_slices, shared, scale_params, seed, rtol, name):
+  from oracle_backend import OracleBackend
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  cfg = FlowConfig(dim=D)
+  params = Params.random(cfg, scale_params, seed=seed, device=dev)
+  eng = FlowEngine(cfg, dev).load(params)
+  pts = eng.normal(seed + 1, B if shared else B * n_slices)
+  if kind_spec.kind == 5:            # NEG_LOGPROB: data points, not base noise
+    pts = pts * 1.5 + 0.3
+  t = np.linspace(0.2, 0.8, n_slices).astype(np.float32)
+  grad = torch.zeros(cfg.param_count(), device=dev)
+  sums = eng.loss_terms_grad(kind_spec, pts, t, B, shared, 1.0, grad)
+  sums_fwd = eng.loss_terms(kind_spec, pts, t, B, shared)
+  assert torch.allclose(sums, sums_fwd, rtol=1e-6, atol=1e-6), (sums, sums_fwd)
+  # a second call accumulates and is deterministic
+  grad2 = torch.zeros_like(grad)
+  eng.loss_terms_grad(kind_spec, pts, t, B, shared, 1.0, grad2)
+  assert torch.equal(grad, grad2)
+  pts64 = pts.cpu()
+  p64 = params.flat.cpu().double().numpy()
+  f = lambda p: float(OracleBackend(cfg, p).loss_terms(kind_spec, pts64, t, B, shared).sum())
+  g_fd, smooth = _fd_grad(f, p64)
+  g = grad.cpu().double().numpy()
+  err = np.abs(g - g_fd)[smooth].max() / max(np.abs(g_fd).max(), 1e-30)
+  first_err = np.abs(g[:16] - g_fd[:16]).max() / max(np.abs(g_fd[:16]).max(), 1e-30)
+  print(f"[grad {name} D={D}] |g|inf={np.abs(g_fd).max():.4g} rel err={err:.2e} (first-spline block {first_err:.2e}; "
+        f"{int((~smooth).sum())} of {g.size} entries at a kink excluded)")
+  assert (~smooth).sum() <= 0.02 * g.size
+  assert err <= rtol, (name, err)
+  return g, g_fd
+
+
+def _spec(kind, **kw):
+  from cnf_ot_amd.applications import _spec as mk
+  return mk(kind, **kw)
+
+
+def test_grad_direct_terms(dev):
+  from cnf_ot_amd import _capi
+  _run(dev, 2, _spec(_capi.TERM_NEG_LOGPROB), 200, 1, True, 0.2, 3, 1e-3, "neg_logprob")
+  for sub in (0, 1, 2):
+    _run(dev, 2, _spec(_capi.TERM_POTENTIAL, subtype=sub, a=1.0), 200, 2, True, 0.2, 4 + sub, 1e-3, f"potential{sub}")
+  _run(dev, 2, _spec(_capi.TERM_REVERSE_KL, T=1.0, beta=4.0), 300, 1, True, 0.2, 8, 1e-3, "reverse_kl")
+
+
+def test_grad_finite_difference_terms(dev):
+  from cnf_ot_amd import _capi
+  _run(dev, 2, _spec(_capi.TERM_KINETIC, dt=0.01), 200, 2, False, 0.2, 9, 5e-3, "kinetic")
+  _run(dev, 2, _spec(_capi.TERM_KINETIC_SCORE, dt=0.01, dx=0.01, coef=0.5), 200, 1, True, 0.2, 10, 5e-3, "kinetic_score")
+  for sub in (0, 1, 2):
+    _run(dev, 2, _spec(_capi.TERM_FLOW_MATCHING, subtype=sub, dt=0.01, dx=0.01, coef=0.5, a=1.0), 128, 1, True, 0.2,
+         11 + sub, 5e-3, f"flow_matching{sub}")
+
+
+def test_grad_other_dims(dev):
+  from cnf_ot_amd import _capi
+  _run(dev, 1, _spec(_capi.TERM_NEG_LOGPROB), 100, 1, True, 0.4, 20, 1e-3, "neg_logprob")
+  _run(dev, 3, _spec(_capi.TERM_FLOW_MATCHING, subtype=3, dt=0.01, dx=0.01, coef=0.5, a=1.0), 64, 1, True, 0.15, 21,
+       5e-3, "flow_matching_lorenz")
+  _run(dev, 3, _spec(_capi.TERM_REVERSE_KL, T=1.0, beta=4.0), 100, 1, True, 0.15, 22, 1e-3, "reverse_kl")
+
+
+def test_value_and_grad_of_composite_losses(dev):
+  """applications.value_and_grad over ot / rwpo / fp losses == finite differences
+  of the same composition over the float64 oracle (a random subset of the
+  parameters, kink-robust reference as above)."""
+  from functools import partial
+  from oracle_backend import OracleModel
+  from cnf_ot_amd import FlowConfig, FlowModel, Params
+  from cnf_ot_amd import applications as app
+  from cnf_ot_amd.distributed import Shard
+  cfg = FlowConfig(dim=2)
+  model, omodel = FlowModel(cfg), OracleModel(cfg)
+  params = Params.random(cfg, 0.2, seed=31, device=dev)
+  B, seed = 256, 5
+  cases = {
+    "ot_obstacle": (partial(app.ot_loss_fn, model, 2, 1.0, 0.01, 2, "obstacle"), partial(app.ot_loss_fn, omodel, 2, 1.0, 0.01, 2, "obstacle")),
+    "rwpo_double_well": (partial(app.rwpo_loss_fn, model, 2, 2.0, 10.0, 0.01, 0.01, 2, "double_well", 1.0),
+                         partial(app.rwpo_loss_fn, omodel, 2, 2.0, 10.0, 0.01, 0.01, 2, "double_well", 1.0)),
+    "fp_gradient": (partial(app.fp_loss_fn, model, 2, 1.0, 1.0, 0.5, 0.01, 0.01, 2, "gradient"),
+                    partial(app.fp_loss_fn, omodel, 2, 1.0, 1.0, 0.5, 0.01, 0.01, 2, "gradient")),
+  }
+  rng = np.random.default_rng(0)
+  idx = np.concatenate([np.arange(16), rng.choice(np.arange(16, cfg.param_count()), 64, replace=False)])
+  for name, (gpu_fn, ora_fn) in cases.items():
+    loss, grads = app.value_and_grad(gpu_fn)(params, seed, 5000.0, B)
+    loss_plain = gpu_fn(params, seed, 5000.0, B)
+    assert abs(float(loss) - float(loss_plain)) <= 1e-6 * abs(float(loss_plain))
+    assert set(grads.keys()) == set(params.keys())                      # haiku tree
+    g = grads.flat.cpu().double().numpy()
+    cpu = Params(cfg, params.flat.cpu().clone())      # only carries cfg: the oracle reads float64 `q`
+    # float32 parameter storage cannot resolve h = 1e-7: differentiate the oracle composition in float64 directly
+    from oracle_backend import OracleBackend
+    p64 = params.flat.cpu().double().numpy()
+
+    class _M:      # OracleModel over raw float64 parameters
+      def __init__(self, q): self.q = q
+      def terms_backend(self, _params, device=None): return OracleBackend(cfg, self.q)
+
+    def loss_at(q):
+      fn = ora_fn.func
+      return float(fn(_M(q), *ora_fn.args[1:], cpu, seed, 5000.0, B, shard=Shard()))
+    ref, ok = np.zeros(idx.size), np.zeros(idx.size, dtype=bool)
+    for n, i in enumerate(idx):
+      vals = []
+      for h in (1e-7, 1e-6):
+        q = p64.copy(); q[i] += h; fp = loss_at(q); q[i] -= 2 * h; vals.append((fp - loss_at(q)) / (2 * h))
+      ref[n] = vals[0]; ok[n] = abs(vals[0] - vals[1]) <= 1e-5 * max(np.abs(g).max(), 1e-30)
+    scale = max(np.abs(ref).max(), np.abs(g[idx]).max())
+    err = np.abs(g[idx] - ref)[ok].max() / scale
+    print(f"[value_and_grad {name}] loss={float(loss):.6g} |g|inf={scale:.4g} rel err={err:.2e} ({int((~ok).sum())} kink entries excluded)")
+    assert err <= 5e-3 and (~ok).sum() <= 4
+
+
+def test_adam_step_and_training_decreases_loss(dev):
+  from cnf_ot_amd import solvers, FlowConfig, Params
+  cfg = FlowConfig(dim=2)
+  p = Params.random(cfg, 0.3, seed=1, device=dev)
+  g = Params.random(cfg, 1.0, seed=2, device=dev)
+  opt = solvers.Adam(1e-3)
+  st = opt.init(p)
+  p0 = p.flat.cpu().double().numpy().copy(); gg = g.flat.cpu().double().numpy()
+  mu = np.zeros_like(p0); nu = np.zeros_like(p0); ref = p0.copy()
+  for step in range(1, 4):       # optax.adam: bias-corrected moments, eps outside the sqrt
+    st = opt.apply(p, g, st)
+    mu = 0.9 * mu + 0.1 * gg; nu = 0.999 * nu + 0.001 * gg * gg
+    ref -= 1e-3 * (mu / (1 - 0.9 ** step)) / (np.sqrt(nu / (1 - 0.999 ** step)) + 1e-8)
+    assert np.abs(p.flat.cpu().double().numpy() - ref).max() <= 2e-6
+  assert st.step == 3
+  # a short OT run from the identity flow: the loss must go down (solvers.py:99-127 in miniature)
+  config = solvers.load_config(overrides={"general": {"type": "ot", "t_batch_size": 2}, "train": {"batch_size": 2048, "lr": 1e-3}})
+  model, params, hist = solvers.train(config, epochs=60)
+  first, last = float(torch.stack(hist[:5]).mean()), float(torch.stack(hist[-5:]).mean())
+  print(f"[train ot] loss {first:.5g} -> {last:.5g} after 60 Adam steps")
+  assert np.isfinite(last) and last < first
