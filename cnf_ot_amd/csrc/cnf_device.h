@@ -341,25 +341,36 @@ template <int N> __device__ __forceinline__ void load_row(uniform_ptr p, float (
 }
 
 // acc[j] += sum_i in[i] * W[i][j] for a wave-uniform row-major W[R][N].
-// The rows are consumed in groups of G: each group is G*N scalar loads
-// (s_load_dwordx16) followed by G*N per-lane FMAs with an SGPR operand.  The
-// scheduling barrier after every group stops hipcc from clustering ALL of the
-// layer's scalar loads at the top (~600 SGPRs -> spilled to VGPR lanes).
-// Scalar-load latency is hidden by the other waves of the SIMD.
+// One row = one s_load_dwordx16 into SGPRs + N per-lane (packed) FMAs with an
+// SGPR operand.  Two things are controlled by hand with scheduling barriers:
+//  * hipcc would cluster ALL of the layer's scalar loads at the top (~600 SGPRs
+//    -> spilled to VGPR lanes); here at most two rows are live;
+//  * scalar loads return out of order, so every wait is lgkmcnt(0): to overlap
+//    the next row's load with this row's FMAs the wait for THIS row must come
+//    first.  Order per row: [first FMA: waits for row i] [issue load of row
+//    i+1] [remaining FMAs].
 template <int R, int N, int G, class T>
 __device__ __forceinline__ void dense_acc(uniform_ptr W, const T (&in)[R], T (&acc)[N]) {
-  static_assert(R % G == 0, "row group must divide the row count");
+  float cur[N];
 #pragma unroll
-  for (int g = 0; g < R / G; ++g) {
-    float wv[G * N];
+  for (int t = 0; t < N; ++t) cur[t] = W[t];
 #pragma unroll
-    for (int t = 0; t < G * N; ++t) wv[t] = W[g * G * N + t];
+  for (int i = 0; i < R; ++i) {
+    acc[0] = vfma(cur[0], in[i], acc[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    float nxt[N];
+    if (i + 1 < R) {
 #pragma unroll
-    for (int r = 0; r < G; ++r) {
-#pragma unroll
-      for (int j = 0; j < N; ++j) acc[j] = vfma(wv[r * N + j], in[g * G + r], acc[j]);
+      for (int t = 0; t < N; ++t) nxt[t] = W[(i + 1) * N + t];
     }
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 1; j < N; ++j) acc[j] = vfma(cur[j], in[i], acc[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + 1 < R) {
+#pragma unroll
+      for (int t = 0; t < N; ++t) cur[t] = nxt[t];
+    }
   }
 }
 
