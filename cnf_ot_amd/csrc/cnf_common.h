@@ -72,6 +72,15 @@ struct CnfModel {
   X(8, 5) X(16, 4) X(16, 5) X(16, 8) X(16, 10) X(32, 5) X(32, 8) X(64, 5)
 #endif
 
+// Dynamic LDS above the 64 KB default needs an explicit opt-in per kernel; the
+// CU has 160 KB.  Returns false if the request cannot be met.
+template <class K>
+static inline bool ensure_lds(K kernel, size_t bytes) {
+  if (bytes > 160 * 1024) return false;
+  if (bytes <= 64 * 1024) return true;
+  return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
 static inline cnf::ModelArgs model_args(const CnfModel* m) {
   cnf::ModelArgs a;
   a.prep = m->prep; a.per_layer = m->per_layer;

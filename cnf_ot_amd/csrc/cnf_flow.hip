@@ -612,6 +612,12 @@ static int samples_per_lane(const CnfModel* m, int64_t B) {
   return (m->fast_math && B >= (int64_t)m->num_cus * 4 * 64 * 2) ? 2 : 1;
 }
 
+#define CNF_LAUNCH(KERNEL, GRID, LDS, STREAM, ARGS)                          \
+  do {                                                                     \
+    if (!ensure_lds(KERNEL, LDS)) return CNF_ERR_UNSUPPORTED;              \
+    hipLaunchKernelGGL(KERNEL, dim3((unsigned)(GRID)), dim3(TILE), LDS, STREAM, ARGS); \
+  } while (0)
+
 template <bool TO_BASE>
 static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stream) {
   const int64_t ts = (int64_t)TILE * spl;
@@ -621,20 +627,15 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
   if (grid > cap) grid = cap;
   const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * ts) * sizeof(float);
   if (m->fast_math && m->use_mfma && m->mfma_off > 0 && m->cfg.hidden_size == 16 && m->cfg.num_bins == 5) {
-    if (spl == 2)
-      hipLaunchKernelGGL((flow_kernel<16, 5, TO_BASE, true, v2f, true>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);
-    else
-      hipLaunchKernelGGL((flow_kernel<16, 5, TO_BASE, true, float, true>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+    if (spl == 2) CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, v2f, true>), grid, lds, stream, a);
+    else CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, float, true>), grid, lds, stream, a);
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
   }
 #define X(HH, KK)                                                                             \
   if (m->cfg.hidden_size == HH && m->cfg.num_bins == KK) {                                    \
-    if (!m->fast_math)                                                                        \
-      hipLaunchKernelGGL((flow_kernel<HH, KK, TO_BASE, false, float>), dim3((unsigned)grid), dim3(TILE), lds, stream, a); \
-    else if (spl == 2)                                                                        \
-      hipLaunchKernelGGL((flow_kernel<HH, KK, TO_BASE, true, v2f>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);    \
-    else                                                                                      \
-      hipLaunchKernelGGL((flow_kernel<HH, KK, TO_BASE, true, float>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);  \
+    if (!m->fast_math) CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, false, float>), grid, lds, stream, a);        \
+    else if (spl == 2) CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, true, v2f>), grid, lds, stream, a);           \
+    else CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, true, float>), grid, lds, stream, a);                       \
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;                            \
   }
   CNF_KERNEL_CONFIGS(X)
@@ -654,7 +655,9 @@ static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, 
   a.B = B; a.c_block = c_block;
   a.aux_mode = aux_mode;
   a.div_magic = m->div_magic;
-  const int spl = m->fast_math ? samples_per_lane(m, B) : 1;
+  int spl = m->fast_math ? samples_per_lane(m, B) : 1;
+  // two samples per lane double the LDS tile: fall back when it would not fit
+  if (spl == 2 && (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * TILE * 2) * sizeof(float) > 160 * 1024) spl = 1;
   if (c_block >= B) a.c_mode = C_SINGLE;
   else if (c_block == 1) a.c_mode = C_PER_SAMPLE;
   else if (c_block % (TILE * spl) == 0) a.c_mode = C_TILE_UNIFORM;
@@ -728,7 +731,7 @@ extern "C" int cnf_loss_terms(CnfModel* m, const CnfLossSpec* spec, const float*
   // five D x TS buffers: keep a workgroup under ~64 KB of LDS
   int spl = (m->fast_math && n_slices * B >= (int64_t)m->num_cus * 4 * 64 * 2) ? 2 : 1;
   if (m->force_spl == 1 || m->force_spl == 2) spl = m->fast_math ? m->force_spl : 1;
-  if (spl == 2 && (size_t)(5 * D * TILE * 2) * sizeof(float) > 96 * 1024) spl = 1;
+  if (spl == 2 && (size_t)(5 * D * TILE * 2) * sizeof(float) > 64 * 1024) spl = 1;
   const int64_t ts = (int64_t)TILE * spl;
   const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 5 * D * ts) * sizeof(float);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
@@ -737,12 +740,9 @@ extern "C" int cnf_loss_terms(CnfModel* m, const CnfLossSpec* spec, const float*
   if (grid > cap) grid = cap;
 #define X(HH, KK)                                                                             \
   if (m->cfg.hidden_size == HH && m->cfg.num_bins == KK) {                                    \
-    if (!m->fast_math)                                                                        \
-      hipLaunchKernelGGL((loss_kernel<HH, KK, false, float>), dim3((unsigned)grid), dim3(TILE), lds, stream, a); \
-    else if (spl == 2)                                                                        \
-      hipLaunchKernelGGL((loss_kernel<HH, KK, true, v2f>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);    \
-    else                                                                                      \
-      hipLaunchKernelGGL((loss_kernel<HH, KK, true, float>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);  \
+    if (!m->fast_math) CNF_LAUNCH((loss_kernel<HH, KK, false, float>), grid, lds, stream, a);                 \
+    else if (spl == 2) CNF_LAUNCH((loss_kernel<HH, KK, true, v2f>), grid, lds, stream, a);                    \
+    else CNF_LAUNCH((loss_kernel<HH, KK, true, float>), grid, lds, stream, a);                                \
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;                            \
   }
   CNF_KERNEL_CONFIGS(X)

@@ -291,3 +291,22 @@ def test_reference_call_surface(dev):
   ocfg = oracle.OracleConfig(D=2)
   y_ref, _ = oracle.forward_logdet(ocfg, p2.flat.cpu().double().numpy(), s.cpu().double().numpy(), [0.3])
   assert _err(y, y_ref).max() <= TOL_Y
+
+
+def test_wide_event_dimension(dev):
+  """Large D: the LDS tile (2 x D x 256 or 512 floats) needs the > 64 KB opt-in
+  and, beyond that, one sample per lane."""
+  import oracle
+  for D, B in ((24, 700), (40, 300)):
+    fcfg, ocfg = _cfg_pair(D=D)
+    rng = np.random.default_rng(D)
+    params = rng.normal(0, 0.05, oracle.param_count(ocfg)).astype(np.float32).astype(np.float64)
+    noise = rng.normal(size=(B, D)).astype(np.float32)
+    eng = _engine(fcfg, params, dev)
+    for spl in (2, 1):
+      eng.set_samples_per_lane(spl)
+      y, lp = eng.sample_logprob(_t(noise, dev), torch.tensor([0.4], device=dev))
+      y_ref, lp_ref = oracle.sample_logprob(ocfg, params, noise.astype(np.float64), [0.4])
+      assert _err(y, y_ref).max() <= TOL_Y and _err(lp, lp_ref).max() <= 5e-5
+    xb, _ = eng.inverse_logdet(y, torch.tensor([0.4], device=dev))
+    assert (xb.cpu() - torch.from_numpy(noise)).abs().max().item() <= 1e-4
