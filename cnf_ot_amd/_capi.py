@@ -57,6 +57,7 @@ SYMBOLS = {
   "cnf_sample_logprob": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
   "cnf_fill_normal": (ctypes.c_int, [_U64, _U64, _I64, _P, _P]),
   "cnf_loss_terms": (ctypes.c_int, [_P, ctypes.POINTER(CnfLossSpec), _P, ctypes.c_int, _P, _I64, _I64, _P, _P]),
+  "cnf_loss_terms_seeded": (ctypes.c_int, [_P, ctypes.POINTER(CnfLossSpec), _U64, _I64, _I64, _P, _I64, _I64, _P, _P]),
   "cnf_grad_supported": (ctypes.c_int, [_CFG]),
   "cnf_grad_enable": (ctypes.c_int, [_P, _I64]),
   "cnf_loss_terms_grad": (ctypes.c_int, [_P, ctypes.POINTER(CnfLossSpec), _P, ctypes.c_int, _P, _I64, _I64,

@@ -297,7 +297,41 @@ struct LossArgs {
   int64_t n_slices;
   int64_t pts_slice_stride;   // samples between slices in pts (0: shared draw)
   uint32_t div_magic;
+  // pts == nullptr: base noise is generated in the kernel (Philox stream of
+  // fill_normal_kernel): sample i of slice s is stream sample first_sample + s * pts_slice_stride + i
+  uint64_t seed;
+  int64_t first_sample;
 };
+
+// One tile of base noise straight into LDS: the tile's TS*D stream elements are
+// contiguous; a thread draws whole Philox blocks (4 normals) and scatters them.
+__device__ __forceinline__ void tile_noise(uint64_t seed, uint64_t first_element, float* U, int D, uint32_t magic,
+                                           int TS, int64_t n_valid_samples) {
+  const int n_el = (int)(n_valid_samples < TS ? n_valid_samples : TS) * D;
+  const uint64_t blk0 = first_element >> 2;
+  const int n_blk = (int)(((first_element + (uint64_t)(TS * D) - 1) >> 2) - blk0) + 1;
+  for (int q = threadIdx.x; q < n_blk; q += TILE) {
+    const uint64_t blk = blk0 + (uint64_t)q;
+    uint32_t u[4];
+    philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), u);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const float u1 = (float)((u[2 * p] >> 8) + 1u) * (1.0f / 16777216.0f);
+      const float u2 = (float)(u[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
+      const float rad = sqrtf(-2.0f * logf(u1));
+      float sn, cs;
+      sincospif(2.0f * u2, &sn, &cs);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int64_t e = (int64_t)((blk << 2) + 2 * p + r) - (int64_t)first_element;
+        if (e >= 0 && e < TS * D) {
+          const int s = magic ? (int)__umulhi((uint32_t)e, magic) : (int)e, d = (int)e - s * D;
+          U[d * TS + s] = e < n_el ? (r == 0 ? rad * cs : rad * sn) : 0.0f;
+        }
+      }
+    }
+  }
+}
 
 template <class T>
 __device__ __forceinline__ void copy_cols(float* dst, const float* src, int D, int TS) {
@@ -352,7 +386,11 @@ __global__ __launch_bounds__(TILE, 2) void loss_kernel(const LossArgs a) {
     const int64_t tile_start = (tile - slice * tiles_per_slice) * TS;
     const int64_t i = tile_start + col;
     __syncthreads();
-    tile_load(a.pts + slice * a.pts_slice_stride * D, Nn, D, a.div_magic, TS, tile_start, a.B);
+    if (a.pts)
+      tile_load(a.pts + slice * a.pts_slice_stride * D, Nn, D, a.div_magic, TS, tile_start, a.B);
+    else
+      tile_noise(a.seed, (uint64_t)(a.first_sample + slice * a.pts_slice_stride + tile_start) * (uint64_t)D, Nn, D,
+                 a.div_magic, TS, a.B - tile_start);
     const float t = a.t[slice];
     __syncthreads();
 
@@ -701,9 +739,10 @@ extern "C" int cnf_fill_normal(uint64_t seed, uint64_t first_element, int64_t n,
 }
 
 
-extern "C" int cnf_loss_terms(CnfModel* m, const CnfLossSpec* spec, const float* pts, int pts_shared,
-                              const float* t, int64_t n_slices, int64_t B, double* sums, void* stream_) {
-  if (!m || !spec || !pts || !t || !sums || n_slices < 0 || B < 0) return CNF_ERR_INVALID;
+static int loss_terms_impl(CnfModel* m, const CnfLossSpec* spec, const float* pts, int64_t slice_stride,
+                           uint64_t seed, int64_t first_sample, const float* t, int64_t n_slices, int64_t B,
+                           double* sums, void* stream_) {
+  if (!m || !spec || !t || !sums || n_slices < 0 || B < 0 || slice_stride < 0 || first_sample < 0) return CNF_ERR_INVALID;
   if (!m->params_set) return CNF_ERR_INVALID;
   if (spec->kind < CNF_TERM_KINETIC || spec->kind > CNF_TERM_NEG_LOGPROB) return CNF_ERR_INVALID;
   const int D = m->cfg.dim;
@@ -726,8 +765,8 @@ extern "C" int cnf_loss_terms(CnfModel* m, const CnfLossSpec* spec, const float*
 
   LossArgs a;
   a.m = model_args(m); a.spec = *spec; a.pts = pts; a.t = t; a.sums = sums;
-  a.B = B; a.n_slices = n_slices; a.pts_slice_stride = pts_shared ? 0 : B;
-  a.div_magic = m->div_magic;
+  a.B = B; a.n_slices = n_slices; a.pts_slice_stride = slice_stride;
+  a.div_magic = m->div_magic; a.seed = seed; a.first_sample = first_sample;
   // five D x TS buffers: keep a workgroup under ~64 KB of LDS
   int spl = (m->fast_math && n_slices * B >= (int64_t)m->num_cus * 4 * 64 * 2) ? 2 : 1;
   if (m->force_spl == 1 || m->force_spl == 2) spl = m->fast_math ? m->force_spl : 1;
@@ -748,4 +787,17 @@ extern "C" int cnf_loss_terms(CnfModel* m, const CnfLossSpec* spec, const float*
   CNF_KERNEL_CONFIGS(X)
 #undef X
   return CNF_ERR_UNSUPPORTED;
+}
+
+extern "C" int cnf_loss_terms(CnfModel* m, const CnfLossSpec* spec, const float* pts, int pts_shared,
+                              const float* t, int64_t n_slices, int64_t B, double* sums, void* stream) {
+  if (!pts) return CNF_ERR_INVALID;
+  return loss_terms_impl(m, spec, pts, pts_shared ? 0 : B, 0, 0, t, n_slices, B, sums, stream);
+}
+
+extern "C" int cnf_loss_terms_seeded(CnfModel* m, const CnfLossSpec* spec, uint64_t seed, int64_t first_sample,
+                                     int64_t slice_stride, const float* t, int64_t n_slices, int64_t B,
+                                     double* sums, void* stream) {
+  if (spec && spec->kind == CNF_TERM_NEG_LOGPROB) return CNF_ERR_INVALID;   // that term takes data points
+  return loss_terms_impl(m, spec, nullptr, slice_stride, seed, first_sample, t, n_slices, B, sums, stream);
 }

@@ -204,6 +204,21 @@ class FlowEngine:
                                             sums.data_ptr(), _stream_ptr(self.device)), "cnf_loss_terms")
     return sums
 
+  def loss_terms_seeded(self, spec, seed, t, B: int, first_sample: int = 0, slice_stride: int = 0) -> torch.Tensor:
+    """cnf_loss_terms_seeded: as `loss_terms`, base noise drawn in the kernel
+    (sample i of slice s = stream sample first_sample + s*slice_stride + i)."""
+    seed, off = seed_to_u64(seed)
+    if not torch.is_tensor(t):
+      t = torch.as_tensor(np.asarray(t, dtype=np.float32))
+    t = t.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+    sums = torch.empty(t.numel(), dtype=torch.float64, device=self.device)
+    if t.numel() > 0:
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_loss_terms_seeded(self._h, _capi.ctypes.byref(spec), seed, off + first_sample,
+                                                   slice_stride, t.data_ptr(), t.numel(), B, sums.data_ptr(),
+                                                   _stream_ptr(self.device)), "cnf_loss_terms_seeded")
+    return sums
+
   def loss_terms_grad(self, spec, pts, t, B: int, shared: bool, scale: float, grad: torch.Tensor) -> torch.Tensor:
     """cnf_loss_terms_grad: like `loss_terms`, and accumulates
     scale * d(sum of the term)/d(params) into `grad` (flat float32 [n_params])."""

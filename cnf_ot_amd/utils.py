@@ -33,6 +33,10 @@ def _mc_energy(model, params, rng, spec, batch_size, t_array, dim, slices_per_la
     ts = t_array[k0:k0 + slices_per_launch]
     # slice k draws its own noise (the key split of utils.py:328): samples
     # [k*batch_size, (k+1)*batch_size) of the seed's stream; this rank's block of each
+    if hasattr(be, "loss_terms_seeded"):      # HIP engine: noise is drawn inside the kernel, never in HBM
+      total += be.loss_terms_seeded(spec, rng, ts, count, first_sample=k0 * batch_size + start,
+                                    slice_stride=batch_size).sum()
+      continue
     noise = torch.empty(len(ts) * count, dim, dtype=torch.float32, device=be.device)
     for j in range(len(ts)):
       noise[j * count:(j + 1) * count] = be.normal(rng, count, first_sample=(k0 + j) * batch_size + start)
@@ -43,7 +47,7 @@ def _mc_energy(model, params, rng, spec, batch_size, t_array, dim, slices_per_la
 
 
 def calc_kinetic_energy(sample_fn, params, rng, batch_size: int = 65536, t_size: int = 10000, dim: int = 1,
-                        slices_per_launch: int = 128, shard: Optional[Shard] = None):
+                        slices_per_launch: int = 1024, shard: Optional[Shard] = None):
   """cnf_ot/utils.py:311-340 (dt = 0.01 hard-coded there, :324)."""
   model = _model_of(sample_fn)
   t_array = np.linspace(0.0, 1.0, t_size)
@@ -53,7 +57,7 @@ def calc_kinetic_energy(sample_fn, params, rng, batch_size: int = 65536, t_size:
 
 def calc_score_kinetic_energy(sample_fn, log_prob_fn, params, T: float = 1, beta: float = 1, dim: int = 1,
                               rng=0, batch_size: int = 65536, t_size: int = 10000,
-                              slices_per_launch: int = 128, shard: Optional[Shard] = None):
+                              slices_per_launch: int = 1024, shard: Optional[Shard] = None):
   """cnf_ot/utils.py:343-389 (dt = dx = 0.01 hard-coded, :360,378)."""
   model = _model_of(sample_fn)
   t_array = np.linspace(0.0, T, t_size)

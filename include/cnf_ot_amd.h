@@ -174,6 +174,17 @@ int cnf_loss_terms(CnfModel *m, const CnfLossSpec *spec, const float *pts,
                    int pts_shared, const float *t, int64_t n_slices, int64_t B,
                    double *sums, void *stream);
 
+/* Same as cnf_loss_terms with the base noise drawn inside the kernel (no noise
+ * tensor in HBM): sample i of slice s is sample (first_sample + s * slice_stride
+ * + i) of the cnf_fill_normal stream of `seed`.  slice_stride = 0: every slice
+ * reuses the same draw (applications.py:392-400); slice_stride = batch size:
+ * each slice its own draw (the key split of utils.py:328).  Not for
+ * CNF_TERM_NEG_LOGPROB (whose points are data). */
+int cnf_loss_terms_seeded(CnfModel *m, const CnfLossSpec *spec, uint64_t seed,
+                          int64_t first_sample, int64_t slice_stride,
+                          const float *t, int64_t n_slices, int64_t B,
+                          double *sums, void *stream);
+
 /* ---- value_and_grad + Adam (cnf_ot/mfc/solvers.py:90-97) -------------------
  * Backward pass of the loss terms, for the reference's network (hidden 16, two
  * hidden layers, 5 bins, dim <= 15): cnf_grad_supported() tells.

@@ -156,3 +156,27 @@ def test_identity_flow_closed_forms_at_full_size(dev):
   assert abs(float(app.reverse_kl_loss_fn(model, 2, 1.0, 4.0, params, 0.0, 1, B))) <= 1e-6
   got = float(app.potential_loss_fn(model, 2, 0.0, "quadratic", params, 1.0, 1, B))
   assert abs(got - float((z.double() ** 2).sum(1).mean() / 2)) <= 1e-6
+
+
+def test_seeded_terms_equal_tensor_terms(dev):
+  """cnf_loss_terms_seeded (noise drawn in the kernel) == cnf_loss_terms on the
+  cnf_fill_normal tensor of the same stream positions."""
+  from cnf_ot_amd import applications as app, _capi
+  for D, scale in ((2, 0.2), (3, 0.15)):
+    model, params, _ = _setup(dev, D=D, scale=scale)
+    be = model.terms_backend(params)
+    B, S, first = 1000, 5, 777          # ragged: partial tiles, unaligned Philox blocks
+    ts = np.linspace(0.1, 0.9, S).astype(np.float32)
+    for spec in (app._spec(_capi.TERM_KINETIC, dt=0.01), app._spec(_capi.TERM_POTENTIAL, subtype=2),
+                 app._spec(_capi.TERM_REVERSE_KL, T=1.0, beta=4.0)):
+      for spl in (1, 2):
+        be.set_samples_per_lane(spl)
+        own = torch.cat([be.normal(9, B, first_sample=first + s * B) for s in range(S)])
+        a = be.loss_terms(spec, own, ts, B, False)
+        b = be.loss_terms_seeded(spec, 9, ts, B, first_sample=first, slice_stride=B)
+        assert torch.allclose(a, b, rtol=1e-12, atol=1e-9), (D, spec.kind, spl, a, b)
+        shared = be.normal(9, B, first_sample=first)
+        a = be.loss_terms(spec, shared, ts, B, True)
+        b = be.loss_terms_seeded(spec, 9, ts, B, first_sample=first, slice_stride=0)
+        assert torch.allclose(a, b, rtol=1e-12, atol=1e-9)
+    be.set_samples_per_lane(0)
