@@ -8,7 +8,7 @@
 namespace cnf {
 
 constexpr int TILE = 256;
-constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
+constexpr double HALF_LOG_2PI = 0.91893853320467274178;
 
 struct ModelArgs {
   const float* prep;     // prepared model buffer
@@ -17,7 +17,16 @@ struct ModelArgs {
   int64_t per_layer_q;   // floats of MFMA-layout weights per flow layer
   int32_t D, L, M;
   SplineConsts sc;
+  SplineConstsT<double> scd;   // the same constants in float64 (exact-mode kernels)
+  const double* tabd;          // float64 copy of the `first` table (inside prep)
 };
+
+template <class R> __device__ __forceinline__ const SplineConstsT<R>& sc_of(const ModelArgs& a);
+template <> __device__ __forceinline__ const SplineConstsT<float>& sc_of<float>(const ModelArgs& a) { return a.sc; }
+template <> __device__ __forceinline__ const SplineConstsT<double>& sc_of<double>(const ModelArgs& a) { return a.scd; }
+template <class R> __device__ __forceinline__ const R* table_of(const ModelArgs& a);
+template <> __device__ __forceinline__ const float* table_of<float>(const ModelArgs& a) { return a.prep; }
+template <> __device__ __forceinline__ const double* table_of<double>(const ModelArgs& a) { return a.tabd; }
 
 // target drift of flow_matching_loss_fn at r (this thread's column `r3`), dim i
 template <class T>
@@ -49,6 +58,8 @@ struct CnfModel {
   // (opaque to callers; see include/cnf_ot_amd.h)
   CnfConfig cfg;
   cnf::SplineConsts sc;
+  cnf::SplineConstsT<double> scd;
+  int64_t tabd_off;       // offset (in floats, 8-byte aligned) of the float64 table inside prep
   float* prep;            // device
   int64_t n_params;
   int64_t per_layer;
@@ -86,6 +97,7 @@ static inline cnf::ModelArgs model_args(const CnfModel* m) {
   a.prep = m->prep; a.per_layer = m->per_layer;
   a.wq = m->mfma_off > 0 ? m->prep + m->mfma_off : nullptr; a.per_layer_q = m->per_layer_q;
   a.D = m->cfg.dim; a.L = m->cfg.num_layers; a.M = m->cfg.mlp_num_layers;
-  a.sc = m->sc;
+  a.sc = m->sc; a.scd = m->scd;
+  a.tabd = reinterpret_cast<const double*>(m->prep + m->tabd_off);
   return a;
 }

@@ -72,24 +72,41 @@ __host__ __device__ constexpr int tab_stride(int K) { return K + 1 < 6 ? 6 : K +
 __host__ __device__ constexpr int tab_off(int field, int K) { return field * tab_stride(K); }
 __host__ __device__ constexpr int hdr_floats(int K) { return (F_COUNT * tab_stride(K) + 3) & ~3; }
 
-struct SplineConsts {
-  float lo, hi;        // range_min, range_max
-  float span_eff;      // (hi - lo) - K * min_bin
-  float min_bin;
-  float min_slope;
-  float sp_offset;     // log(exp(1 - min_slope) - 1)
+template <class R> struct SplineConstsT {
+  R lo, hi;        // range_min, range_max
+  R span_eff;      // (hi - lo) - K * min_bin
+  R min_bin;
+  R min_slope;
+  R sp_offset;     // log(exp(1 - min_slope) - 1)
 };
+typedef SplineConstsT<float> SplineConsts;
 
 // ---------------------------------------------------------------------------
 // Elementwise helpers over T in {float, v2f}
 // ---------------------------------------------------------------------------
+// T = double is the reference's own dtype (jax_enable_x64, solvers.py:23): one
+// sample per lane, ocml math, float64 table / constants / IO.  It exists for
+// exact-mode parity (1e-12 vs the oracle), not for speed.
 template <class T> struct Lanes;
-template <> struct Lanes<float> { static constexpr int N = 1; typedef int index; };
-template <> struct Lanes<v2f> { static constexpr int N = 2; typedef v2i index; };
+template <> struct Lanes<float> { static constexpr int N = 1; typedef int index; typedef float real; };
+template <> struct Lanes<v2f> { static constexpr int N = 2; typedef v2i index; typedef float real; };
+template <> struct Lanes<double> { static constexpr int N = 1; typedef int index; typedef double real; };
 
-template <class T> __device__ __forceinline__ T splat(float a);
-template <> __device__ __forceinline__ float splat<float>(float a) { return a; }
-template <> __device__ __forceinline__ v2f splat<v2f>(float a) { return v2f{a, a}; }
+template <class T, class A> __device__ __forceinline__ T splat(A a) {
+  if constexpr (std::is_same<T, v2f>::value) return v2f{(float)a, (float)a};
+  else return (T)a;
+}
+
+__device__ __forceinline__ double vfma(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ double vfma(float a, double b, double c) { return fma((double)a, b, c); }
+__device__ __forceinline__ double vmax(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ double vabs(double a) { return fabs(a); }
+__device__ __forceinline__ double vrelu(double a) { return fmax(a, 0.0); }
+__device__ __forceinline__ double clip01(double z) { return fmin(fmax(z, 0.0), 1.0); }
+__device__ __forceinline__ bool vge(double a, double b) { return a >= b; }
+__device__ __forceinline__ bool vle(double a, double b) { return a <= b; }
+__device__ __forceinline__ bool vlt(double a, double b) { return a < b; }
+__device__ __forceinline__ double vsel(bool m, double a, double b) { return m ? a : b; }
 
 __device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
@@ -135,6 +152,11 @@ template <> struct Math<false> {
   static __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
   static __device__ __forceinline__ float div(float a, float b) { return a / b; }
   static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
+  static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+  static __device__ __forceinline__ double log(double x) { return ::log(x); }
+  static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+  static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+  static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ v2f exp(v2f x) { return v2f{expf(x.x), expf(x.y)}; }
   static __device__ __forceinline__ v2f log(v2f x) { return v2f{logf(x.x), logf(x.y)}; }
   static __device__ __forceinline__ v2f rcp(v2f x) { return v2f{1.0f / x.x, 1.0f / x.y}; }
@@ -175,14 +197,21 @@ template <> struct Math<true> {
 
 // softplus(t + offset) + m  (distrax _normalize_knot_slopes)
 template <bool FAST, class T>
-__device__ __forceinline__ T knot_slope(T t, const SplineConsts& sc) {
+__device__ __forceinline__ T knot_slope(T t, const SplineConstsT<typename Lanes<T>::real>& sc) {
   const T v = t + sc.sp_offset;
   const T e = Math<FAST>::exp(-vabs(v));
   // log1p(e), e in (0,1].  Both forms are evaluated and selected: a branch
   // here would split the wave's straight-line code.
-  const T l_log = Math<FAST>::log(e + 1.0f);
-  const T l_ser = vfma(e * -0.5f, e, e);
-  const T l = vsel(vlt(e, 1e-4f), l_ser, l_log);
+  typedef typename Lanes<T>::real R;
+  // float64: log1p proper (the oracle / distrax use softplus = logaddexp)
+  T l;
+  if constexpr (std::is_same<T, double>::value) {
+    l = ::log1p(e);
+  } else {
+    const T l_log = Math<FAST>::log(e + 1.0f);
+    const T l_ser = vfma(e * -0.5f, e, e);
+    l = vsel(vlt(e, (R)1e-4f), l_ser, l_log);
+  }
   return vrelu(v) + l + sc.min_slope;
 }
 
@@ -220,7 +249,7 @@ __device__ __forceinline__ void rqs_bin_eval(T v, T x0, T y0, T bw, T bh, T ibw,
 // Spline of the shared `first` parameters: per-lane bin index, LDS gather of
 // the bin's pre-normalised constants.  `tab` is the prepared header in LDS.
 // ---------------------------------------------------------------------------
-template <int K> __device__ __forceinline__ int bin_of(const float* pos, float v) {
+template <int K, class R> __device__ __forceinline__ int bin_of(const R* pos, R v) {
   int k = 0;
 #pragma unroll
   for (int j = 1; j < K; ++j) k += (v >= pos[j]) ? 1 : 0;
@@ -229,7 +258,7 @@ template <int K> __device__ __forceinline__ int bin_of(const float* pos, float v
 template <int K> __device__ __forceinline__ v2i bin_of(const float* pos, v2f v) {
   return v2i{bin_of<K>(pos, v.x), bin_of<K>(pos, v.y)};
 }
-template <int K> __device__ __forceinline__ float gather(const float* tab, int f, int k) {
+template <int K, class R> __device__ __forceinline__ R gather(const R* tab, int f, int k) {
   return tab[tab_off(f, K) + k];
 }
 template <int K> __device__ __forceinline__ v2f gather(const float* tab, int f, v2i k) {
@@ -237,8 +266,10 @@ template <int K> __device__ __forceinline__ v2f gather(const float* tab, int f, 
 }
 
 template <int K, bool INV, bool FAST, class T>
-__device__ __forceinline__ void table_spline(const float* tab, T v, const SplineConsts& sc, T& out, T& ld) {
-  const float* pos = tab + tab_off(INV ? F_YK : F_XK, K);
+__device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab, T v,
+                                             const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld) {
+  typedef typename Lanes<T>::real R;
+  const R* pos = tab + tab_off(INV ? F_YK : F_XK, K);
   const typename Lanes<T>::index k = bin_of<K>(pos, v);
   rqs_bin_eval<INV, FAST, T>(v, gather<K>(tab, F_X0, k), gather<K>(tab, F_Y0, k), gather<K>(tab, F_BW, k),
                              gather<K>(tab, F_BH, k), gather<K>(tab, F_IBW, k), gather<K>(tab, F_IBH, k),
@@ -247,7 +278,7 @@ __device__ __forceinline__ void table_spline(const float* tab, T v, const Spline
   const auto below = vle(v, sc.lo);
   const auto above = vge(v, sc.hi);
   if (vany(below) || vany(above)) {      // linear tails (rare: |v| >= 10)
-    const float* tl = tab + tab_off(F_TAIL, K);
+    const R* tl = tab + tab_off(F_TAIL, K);
     const T lo_out = INV ? vfma(v - sc.lo, splat<T>(tl[T_INV_DLO]), splat<T>(sc.lo))
                          : vfma(v - sc.lo, splat<T>(tl[T_DLO]), splat<T>(sc.lo));
     const T hi_out = INV ? vfma(v - sc.hi, splat<T>(tl[T_INV_DHI]), splat<T>(sc.hi))
@@ -266,8 +297,8 @@ __device__ __forceinline__ void table_spline(const float* tab, T v, const Spline
 // slopes of the selected bin are normalised (2 softplus instead of K+1).
 // ---------------------------------------------------------------------------
 template <int K, bool INV, bool FAST, class T>
-__device__ __forceinline__ void cond_spline(const T (&th)[3 * K + 1], T v, const SplineConsts& sc,
-                                            T& out, T& ld) {
+__device__ __forceinline__ void cond_spline(const T (&th)[3 * K + 1], T v,
+                                            const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld) {
   using M = Math<FAST>;
   T mw = th[0], mh = th[K];
 #pragma unroll
@@ -335,6 +366,11 @@ template <int N> __device__ __forceinline__ void materialize(v2f (&v)[N]) {
   for (int j = 0; j < N; ++j) asm volatile("" : "+v"(v[j]));
 }
 
+template <int N> __device__ __forceinline__ void materialize(double (&v)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) asm volatile("" : "+v"(v[j]));
+}
+
 template <int N> __device__ __forceinline__ void load_row(uniform_ptr p, float (&v)[N]) {
 #pragma unroll
   for (int j = 0; j < N; ++j) v[j] = p[j];
@@ -377,10 +413,14 @@ __device__ __forceinline__ void dense_acc(uniform_ptr W, const T (&in)[R], T (&a
 constexpr int row_group(int R, int N) { return 1; }
 
 // this thread's value(s) of input dimension `idx` in its LDS column
-template <class T> __device__ __forceinline__ T lds_get(const float* col, int idx, int stride);
+template <class T> __device__ __forceinline__ T lds_get(const typename Lanes<T>::real* col, int idx, int stride);
 template <> __device__ __forceinline__ float lds_get<float>(const float* col, int idx, int stride) {
   return col[idx * stride];
 }
+template <> __device__ __forceinline__ double lds_get<double>(const double* col, int idx, int stride) {
+  return col[idx * stride];
+}
+__device__ __forceinline__ void lds_put(double* col, int idx, int stride, double v) { col[idx * stride] = v; }
 template <> __device__ __forceinline__ v2f lds_get<v2f>(const float* col, int idx, int stride) {
   return *reinterpret_cast<const v2f*>(col + idx * stride);
 }
@@ -390,7 +430,7 @@ __device__ __forceinline__ void lds_put(float* col, int idx, int stride, v2f v) 
 }
 
 template <int H, int P, class T>
-__device__ __forceinline__ void conditioner(uniform_ptr w, int d, int M, T c, const float* col,
+__device__ __forceinline__ void conditioner(uniform_ptr w, int d, int M, T c, const typename Lanes<T>::real* col,
                                             int first_idx, int idx_step, int stride, T (&th)[P]) {
   T h[H];
   w = launder(w);

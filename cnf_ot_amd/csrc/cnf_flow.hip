@@ -28,17 +28,19 @@ enum CMode { C_SINGLE = 0, C_PER_SAMPLE = 1, C_TILE_UNIFORM = 2, C_GENERIC = 3 }
 enum AuxMode { AUX_LOGDET = 0, AUX_LOGPROB = 1 };
 
 
-struct FlowArgs {
+template <class R> struct FlowArgsT {
   ModelArgs m;
-  const float* in;       // [B, D]
-  const float* c;        // conditions
-  float* out;            // [B, D] or null
-  float* aux;            // [B] logdet / logprob, or null
+  const R* in;           // [B, D]
+  const R* c;            // conditions
+  R* out;                // [B, D] or null
+  R* aux;                // [B] logdet / logprob, or null
   int64_t B;
   int64_t c_block;
   int32_t c_mode, aux_mode;
   int32_t div_magic;     // ceil(2^32 / D): e / D == umulhi(e, magic) for e < 2^16
 };
+typedef FlowArgsT<float> FlowArgs;
+typedef FlowArgsT<double> FlowArgsD;
 
 // ---------------------------------------------------------------------------
 // prepare_kernel: params (flat, caller-owned) -> prepared model buffer.
@@ -48,7 +50,7 @@ struct FlowArgs {
 __global__ void prepare_kernel(const float* __restrict__ params, float* __restrict__ prep,
                                int K, int64_t n_params, double lo, double hi, double min_bin,
                                double min_slope, int D, int L, int M, int64_t per_layer,
-                               int64_t per_layer_q, int64_t mfma_off) {
+                               int64_t per_layer_q, int64_t mfma_off, int64_t tabd_off) {
   const int P = 3 * K + 1;
   const int hdr = hdr_floats(K);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_params - P;
@@ -106,9 +108,16 @@ __global__ void prepare_kernel(const float* __restrict__ params, float* __restri
     const double v = (double)params[2 * K + k] + offset;
     dl[k] = fmax(v, 0.0) + log1p(exp(-fabs(v))) + min_slope;
   }
-  for (int i = 0; i < hdr; ++i) prep[i] = 0.0f;
+  double* td = reinterpret_cast<double*>(prep + tabd_off);     // the same table in float64
+  for (int i = 0; i < hdr; ++i) { prep[i] = 0.0f; td[i] = 0.0; }
   for (int k = 0; k < K; ++k) {
     const double bw = xk[k + 1] - xk[k], bh = yk[k + 1] - yk[k], s = bh / bw;
+    td[tab_off(F_X0, K) + k] = xk[k];            td[tab_off(F_Y0, K) + k] = yk[k];
+    td[tab_off(F_BW, K) + k] = bw;               td[tab_off(F_BH, K) + k] = bh;
+    td[tab_off(F_IBW, K) + k] = 1.0 / bw;        td[tab_off(F_IBH, K) + k] = 1.0 / bh;
+    td[tab_off(F_S, K) + k] = s;                 td[tab_off(F_ST, K) + k] = dl[k + 1] + dl[k] - 2.0 * s;
+    td[tab_off(F_D0, K) + k] = dl[k];            td[tab_off(F_D1, K) + k] = dl[k + 1];
+    td[tab_off(F_L2S, K) + k] = 2.0 * log(s);
     prep[tab_off(F_X0, K) + k] = (float)xk[k];
     prep[tab_off(F_Y0, K) + k] = (float)yk[k];
     prep[tab_off(F_BW, K) + k] = (float)bw;
@@ -124,7 +133,13 @@ __global__ void prepare_kernel(const float* __restrict__ params, float* __restri
   for (int k = 0; k <= K; ++k) {
     prep[tab_off(F_XK, K) + k] = (float)xk[k];
     prep[tab_off(F_YK, K) + k] = (float)yk[k];
+    td[tab_off(F_XK, K) + k] = xk[k];
+    td[tab_off(F_YK, K) + k] = yk[k];
   }
+  double* tld = td + tab_off(F_TAIL, K);
+  tld[T_DLO] = dl[0];            tld[T_DHI] = dl[K];
+  tld[T_LOG_DLO] = log(dl[0]);   tld[T_LOG_DHI] = log(dl[K]);
+  tld[T_INV_DLO] = 1.0 / dl[0];  tld[T_INV_DHI] = 1.0 / dl[K];
   float* tl = prep + tab_off(F_TAIL, K);
   tl[T_DLO] = (float)dl[0];             tl[T_DHI] = (float)dl[K];
   tl[T_LOG_DLO] = (float)log(dl[0]);    tl[T_LOG_DHI] = (float)log(dl[K]);
@@ -139,17 +154,19 @@ __global__ void prepare_kernel(const float* __restrict__ params, float* __restri
 // ---------------------------------------------------------------------------
 // e / D for e < 2^16 (a tile has at most 512 * 64 elements): one v_mul_hi_u32
 // instead of the ~20-instruction 32-bit division sequence.
-__device__ __forceinline__ void tile_load(const float* __restrict__ g, float* U, int D, uint32_t magic, int TS,
+template <class R>
+__device__ __forceinline__ void tile_load(const R* __restrict__ g, R* U, int D, uint32_t magic, int TS,
                                           int64_t tile_start, int64_t B) {
   const int64_t base = tile_start * D;
   const int n_el = (int)(B - tile_start < TS ? B - tile_start : TS) * D;
   for (int e = threadIdx.x; e < TS * D; e += TILE) {
     const int s = magic ? (int)__umulhi((uint32_t)e, magic) : e, d = e - s * D;   // magic 0: D = 1
-    U[d * TS + s] = e < n_el ? g[base + e] : 0.0f;
+    U[d * TS + s] = e < n_el ? g[base + e] : (R)0;
   }
 }
 
-__device__ __forceinline__ void tile_store(float* __restrict__ g, const float* U, int D, uint32_t magic, int TS,
+template <class R>
+__device__ __forceinline__ void tile_store(R* __restrict__ g, const R* U, int D, uint32_t magic, int TS,
                                            int64_t tile_start, int64_t B) {
   const int64_t base = tile_start * D;
   const int n_el = (int)(B - tile_start < TS ? B - tile_start : TS) * D;
@@ -159,16 +176,20 @@ __device__ __forceinline__ void tile_store(float* __restrict__ g, const float* U
   }
 }
 
-__device__ __forceinline__ float load_cond1(const FlowArgs& a, int64_t tile_start, int64_t i) {
+template <class R>
+__device__ __forceinline__ R load_cond1(const FlowArgsT<R>& a, int64_t tile_start, int64_t i) {
   switch (a.c_mode) {
     case C_SINGLE: return a.c[0];
-    case C_PER_SAMPLE: return i < a.B ? a.c[i] : 0.0f;
+    case C_PER_SAMPLE: return i < a.B ? a.c[i] : (R)0;
     case C_TILE_UNIFORM: return a.c[tile_start / a.c_block];
-    default: return i < a.B ? a.c[i / a.c_block] : 0.0f;
+    default: return i < a.B ? a.c[i / a.c_block] : (R)0;
   }
 }
-template <class T> __device__ __forceinline__ T load_cond(const FlowArgs& a, int64_t tile_start, int64_t i);
+template <class T> __device__ __forceinline__ T load_cond(const FlowArgsT<typename Lanes<T>::real>& a, int64_t tile_start, int64_t i);
 template <> __device__ __forceinline__ float load_cond<float>(const FlowArgs& a, int64_t ts, int64_t i) {
+  return load_cond1(a, ts, i);
+}
+template <> __device__ __forceinline__ double load_cond<double>(const FlowArgsD& a, int64_t ts, int64_t i) {
   return load_cond1(a, ts, i);
 }
 template <> __device__ __forceinline__ v2f load_cond<v2f>(const FlowArgs& a, int64_t ts, int64_t i) {
@@ -186,7 +207,10 @@ __device__ __forceinline__ v2f hsum(v2f v) { return v; }
 // already-produced outputs: conditional.py:159-167, autoregressive.py:76-107).
 // Returns the accumulated log|det J|; the result is left in `U` (swapped).
 template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false>
-__device__ __forceinline__ T flow_pass(const ModelArgs& a, const float* tab, float*& U, float*& O, T c) {
+__device__ __forceinline__ T flow_pass(const ModelArgs& a, const typename Lanes<T>::real* tab,
+                                       typename Lanes<T>::real*& U, typename Lanes<T>::real*& O, T c) {
+  typedef typename Lanes<T>::real R;
+  const SplineConstsT<R>& sc = sc_of<R>(a);
   static_assert(!MFMA || (H == 16 && K == 5), "the MFMA conditioner is built for H = 16, P = 16");
   constexpr int P = 3 * K + 1;
   constexpr bool INV = !TO_BASE;
@@ -199,10 +223,10 @@ __device__ __forceinline__ T flow_pass(const ModelArgs& a, const float* tab, flo
     const int l = TO_BASE ? a.L - 1 - step : step;
     const bool odd = l & 1;                       // flows.py:141-143 perms
     const int first_idx = odd ? D - 1 : 0, idx_step = odd ? -1 : 1;
-    float* cu = U + SPL * threadIdx.x;
-    float* co = O + SPL * threadIdx.x;
+    R* cu = U + SPL * threadIdx.x;
+    R* co = O + SPL * threadIdx.x;
     T o, ld;
-    table_spline<K, INV, FAST, T>(tab, lds_get<T>(cu, first_idx, TS), a.sc, o, ld);
+    table_spline<K, INV, FAST, T>(tab, lds_get<T>(cu, first_idx, TS), sc, o, ld);
     lds_put(co, first_idx, TS, o);
     acc += ld;
     uniform_ptr w = weights + l * a.per_layer;
@@ -210,30 +234,34 @@ __device__ __forceinline__ T flow_pass(const ModelArgs& a, const float* tab, flo
     for (int d = 1; d < D; ++d) {
       const int i = first_idx + d * idx_step;
       T th[P];
-      if constexpr (MFMA) {
+      if constexpr (MFMA && !std::is_same<T, double>::value) {
         conditioner_mfma<T>(reinterpret_cast<const f4*>(wq), d, a.M, c, TO_BASE ? co : cu, first_idx, idx_step, TS, th);
         wq += cond_floats_mfma(d, a.M);
       } else {
         conditioner<H, P, T>(w, d, a.M, c, TO_BASE ? co : cu, first_idx, idx_step, TS, th);
         w += cond_floats(d, H, a.M, P);
       }
-      cond_spline<K, INV, FAST, T>(th, lds_get<T>(cu, i, TS), a.sc, o, ld);
+      cond_spline<K, INV, FAST, T>(th, lds_get<T>(cu, i, TS), sc, o, ld);
       lds_put(co, i, TS, o);
       acc += ld;
     }
-    float* t = U; U = O; O = t;
+    R* t = U; U = O; O = t;
   }
   return acc;
 }
 
 template <class T>
-__device__ __forceinline__ T base_logprob(const float* col, int D, int TS) {
+__device__ __forceinline__ T base_logprob(const typename Lanes<T>::real* col, int D, int TS) {
+  typedef typename Lanes<T>::real R;
   T b = splat<T>(0.0f);
-  for (int d = 0; d < D; ++d) { const T x = lds_get<T>(col, d, TS); b = vfma(x * -0.5f, x, b); }
-  return b - D * HALF_LOG_2PI;
+  for (int d = 0; d < D; ++d) { const T x = lds_get<T>(col, d, TS); b = vfma(x * (R)-0.5, x, b); }
+  return b - (R)(D * HALF_LOG_2PI);
 }
 
 __device__ __forceinline__ void store_aux(float* aux, int64_t i, int64_t B, float r) {
+  if (i < B) aux[i] = r;
+}
+__device__ __forceinline__ void store_aux(double* aux, int64_t i, int64_t B, double r) {
   if (i < B) aux[i] = r;
 }
 __device__ __forceinline__ void store_aux(float* aux, int64_t i, int64_t B, v2f r) {
@@ -242,22 +270,24 @@ __device__ __forceinline__ void store_aux(float* aux, int64_t i, int64_t B, v2f 
 }
 
 template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false>
-__global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename Lanes<T>::real> a) {
+  typedef typename Lanes<T>::real R;
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  R* lds = reinterpret_cast<R*>(lds_raw);
   constexpr int HDR = hdr_floats(K);
   constexpr int SPL = Lanes<T>::N;
   constexpr int TS = TILE * SPL;
-  float* tab = lds;
-  float* U = lds + HDR;
-  float* O = U + a.m.D * TS;
-  for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = a.m.prep[i];
+  R* tab = lds;
+  R* U = lds + HDR;
+  R* O = U + a.m.D * TS;
+  for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = table_of<R>(a.m)[i];
 
   const int64_t n_tiles = (a.B + TS - 1) / TS;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t tile_start = tile * TS;
     const int64_t i = tile_start + SPL * threadIdx.x;
     __syncthreads();                       // previous tile's stores are done with U/O
-    tile_load(a.in, U, a.m.D, a.div_magic, TS, tile_start, a.B);
+    tile_load<R>(a.in, U, a.m.D, a.div_magic, TS, tile_start, a.B);
     const T c = load_cond<T>(a, tile_start, i);
     __syncthreads();
 
@@ -274,7 +304,7 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgs a) {
     }
     if (a.out) {
       __syncthreads();
-      tile_store(a.out, U, a.m.D, a.div_magic, TS, tile_start, a.B);
+      tile_store<R>(a.out, U, a.m.D, a.div_magic, TS, tile_start, a.B);
     }
   }
 }
@@ -387,7 +417,7 @@ __global__ __launch_bounds__(TILE, 2) void loss_kernel(const LossArgs a) {
     const int64_t i = tile_start + col;
     __syncthreads();
     if (a.pts)
-      tile_load(a.pts + slice * a.pts_slice_stride * D, Nn, D, a.div_magic, TS, tile_start, a.B);
+      tile_load<float>(a.pts + slice * a.pts_slice_stride * D, Nn, D, a.div_magic, TS, tile_start, a.B);
     else
       tile_noise(a.seed, (uint64_t)(a.first_sample + slice * a.pts_slice_stride + tile_start) * (uint64_t)D, Nn, D,
                  a.div_magic, TS, a.B - tile_start);
@@ -591,7 +621,13 @@ extern "C" int cnf_model_create(const CnfConfig* cfg, CnfModel** out) {
     m->mfma_off = (hdr_floats(K) + (m->n_params - P) + 3) & ~(int64_t)3;
     q_floats = (size_t)m->per_layer_q * cfg->num_layers;
   }
-  const size_t bytes = (size_t)(hdr_floats(K) + (m->n_params - P) + 4 + q_floats) * sizeof(float) + 64;
+  // float64 copy of the `first` table (exact-mode kernels), 8-byte aligned, after everything else
+  m->tabd_off = (hdr_floats(K) + (m->n_params - P) + 4 + (int64_t)q_floats + 1) & ~(int64_t)1;
+  const size_t bytes = (size_t)(m->tabd_off + 2 * hdr_floats(K)) * sizeof(float) + 64;
+  m->scd.lo = (double)cfg->range_min; m->scd.hi = (double)cfg->range_max;
+  m->scd.min_bin = (double)cfg->min_bin_size; m->scd.min_slope = (double)cfg->min_knot_slope;
+  m->scd.span_eff = (m->scd.hi - m->scd.lo) - (double)K * m->scd.min_bin;
+  m->scd.sp_offset = log(exp(1.0 - m->scd.min_slope) - 1.0);
   if (hipMalloc((void**)&m->prep, bytes) != hipSuccess) { delete m; return CNF_ERR_NOMEM; }
   *out = m;
   return CNF_OK;
@@ -636,7 +672,8 @@ extern "C" int cnf_model_set_params(CnfModel* m, const float* params, void* stre
   hipLaunchKernelGGL(prepare_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, m->prep, K,
                      m->n_params, (double)m->cfg.range_min, (double)m->cfg.range_max,
                      (double)m->cfg.min_bin_size, (double)m->cfg.min_knot_slope, m->cfg.dim,
-                     m->cfg.num_layers, m->cfg.mlp_num_layers, m->per_layer, m->per_layer_q, m->mfma_off);
+                     m->cfg.num_layers, m->cfg.mlp_num_layers, m->per_layer, m->per_layer_q, m->mfma_off,
+                     m->tabd_off);
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
   m->params_set = 1;
   return CNF_OK;
@@ -800,4 +837,61 @@ extern "C" int cnf_loss_terms_seeded(CnfModel* m, const CnfLossSpec* spec, uint6
                                      double* sums, void* stream) {
   if (spec && spec->kind == CNF_TERM_NEG_LOGPROB) return CNF_ERR_INVALID;   // that term takes data points
   return loss_terms_impl(m, spec, nullptr, slice_stride, seed, first_sample, t, n_slices, B, sums, stream);
+}
+
+// ---- float64 instantiation: the reference's own dtype (solvers.py:23) ---------
+// Exact-mode entry points: double IO, double table/constants, ocml math, one
+// sample per lane.  Parameters stay the float32 vector given to
+// cnf_model_set_params (each weight is widened exactly).
+template <bool TO_BASE>
+static int launch_flow_f64(CnfModel* m, const FlowArgsD& a, hipStream_t stream) {
+  const int64_t n_tiles = (a.B + TILE - 1) / TILE;
+  int64_t grid = n_tiles;
+  const int64_t cap = (int64_t)m->num_cus * 8;
+  if (grid > cap) grid = cap;
+  const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * TILE) * sizeof(double);
+#define X(HH, KK)                                                                    \
+  if (m->cfg.hidden_size == HH && m->cfg.num_bins == KK) {                           \
+    CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, false, double>), grid, lds, stream, a); \
+    return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;                   \
+  }
+  CNF_KERNEL_CONFIGS(X)
+#undef X
+  return CNF_ERR_UNSUPPORTED;
+}
+
+static int run_flow_f64(CnfModel* m, bool to_base, const double* in, const double* c, int64_t c_block,
+                        double* out, double* aux, int aux_mode, int64_t B, void* stream) {
+  if (!m || !in || !c || B < 0 || c_block < 1) return CNF_ERR_INVALID;
+  if (!out && !aux) return CNF_ERR_INVALID;
+  if (!m->params_set) return CNF_ERR_INVALID;
+  if (B == 0) return CNF_OK;
+  FlowArgsD a;
+  a.m = model_args(m);
+  a.in = in; a.c = c; a.out = out; a.aux = aux;
+  a.B = B; a.c_block = c_block; a.aux_mode = aux_mode; a.div_magic = m->div_magic;
+  if (c_block >= B) a.c_mode = C_SINGLE;
+  else if (c_block == 1) a.c_mode = C_PER_SAMPLE;
+  else if (c_block % TILE == 0) a.c_mode = C_TILE_UNIFORM;
+  else a.c_mode = C_GENERIC;
+  return to_base ? launch_flow_f64<true>(m, a, (hipStream_t)stream) : launch_flow_f64<false>(m, a, (hipStream_t)stream);
+}
+
+extern "C" int cnf_forward_logdet_f64(CnfModel* m, const double* x, const double* c, int64_t c_block, double* y,
+                                      double* logdet, int64_t B, void* stream) {
+  return run_flow_f64(m, false, x, c, c_block, y, logdet, AUX_LOGDET, B, stream);
+}
+extern "C" int cnf_inverse_logdet_f64(CnfModel* m, const double* y, const double* c, int64_t c_block, double* x,
+                                      double* logdet, int64_t B, void* stream) {
+  return run_flow_f64(m, true, y, c, c_block, x, logdet, AUX_LOGDET, B, stream);
+}
+extern "C" int cnf_log_prob_f64(CnfModel* m, const double* value, const double* c, int64_t c_block, double* logp,
+                                int64_t B, void* stream) {
+  if (!logp) return CNF_ERR_INVALID;
+  return run_flow_f64(m, true, value, c, c_block, nullptr, logp, AUX_LOGPROB, B, stream);
+}
+extern "C" int cnf_sample_logprob_f64(CnfModel* m, const double* noise, const double* c, int64_t c_block, double* y,
+                                      double* logp, int64_t B, void* stream) {
+  if (!y) return CNF_ERR_INVALID;
+  return run_flow_f64(m, false, noise, c, c_block, y, logp, AUX_LOGPROB, B, stream);
 }

@@ -105,20 +105,23 @@ class FlowEngine:
     _capi.check(self.lib.cnf_model_set_samples_per_lane(self._h, int(spl)), "cnf_model_set_samples_per_lane")
 
   # -- helpers ---------------------------------------------------------------
-  def _points(self, t, what) -> torch.Tensor:
+  def _points(self, t, what, keep_f64=False) -> torch.Tensor:
+    """float64 points select the float64 kernels (the reference's dtype:
+    exact-mode parity, slower); everything else runs in float32."""
     if not torch.is_tensor(t):
       t = torch.as_tensor(np.asarray(t))
     if t.dim() != 2 or t.shape[1] != self.cfg.dim:
       # the reference checks the event shape at trace time (autoregressive.py:80,113)
       raise ValueError(f"{what}: expected shape [B, {self.cfg.dim}], got {tuple(t.shape)}")
-    return t.to(device=self.device, dtype=torch.float32).contiguous()
+    dtype = torch.float64 if (keep_f64 and t.dtype == torch.float64) else torch.float32
+    return t.to(device=self.device, dtype=dtype).contiguous()
 
-  def cond(self, cond, B: int) -> Tuple[torch.Tensor, int]:
-    """cond -> (flat float32 device tensor, c_block).  [B,1]/[B]: per sample;
+  def cond(self, cond, B: int, dtype=torch.float32) -> Tuple[torch.Tensor, int]:
+    """cond -> (flat device tensor, c_block).  [B,1]/[B]: per sample;
     scalar/[1]: broadcast; [S]/[S,1] with B % S == 0: S equal slices."""
     if not torch.is_tensor(cond):
-      cond = torch.as_tensor(np.asarray(cond, dtype=np.float32))
-    c = cond.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+      cond = torch.as_tensor(np.asarray(cond, dtype=np.float64))
+    c = cond.to(device=self.device, dtype=dtype).reshape(-1).contiguous()
     n = c.numel()
     if n == 0:
       raise ValueError("cond is empty")
@@ -130,23 +133,25 @@ class FlowEngine:
       return c, B // n
     raise ValueError(f"cond with {n} values does not tile a batch of {B}")
 
-  def _check_out(self, t, shape, what):
-    if (t.dtype != torch.float32 or t.device != self.device or not t.is_contiguous()
+  def _check_out(self, t, shape, what, dtype=torch.float32):
+    if (t.dtype != dtype or t.device != self.device or not t.is_contiguous()
         or tuple(t.shape) != tuple(shape)):
-      raise ValueError(f"{what}: need a contiguous float32 {tuple(shape)} tensor on {self.device}")
+      raise ValueError(f"{what}: need a contiguous {dtype} {tuple(shape)} tensor on {self.device}")
     return t
 
   def _run(self, fn, name, pts, cond, want_pts, want_aux, out=None, aux=None):
     B = pts.shape[0]
-    c, c_block = self.cond(cond, B)
+    if pts.dtype == torch.float64:
+      fn, name = getattr(self.lib, name + "_f64"), name + "_f64"
+    c, c_block = self.cond(cond, B, pts.dtype)
     if out is not None:
-      self._check_out(out, pts.shape, name + " out")
+      self._check_out(out, pts.shape, name + " out", pts.dtype)
     elif want_pts:
       out = torch.empty_like(pts)
     if aux is not None:
-      self._check_out(aux, (B,), name + " aux")
+      self._check_out(aux, (B,), name + " aux", pts.dtype)
     elif want_aux:
-      aux = torch.empty(B, dtype=torch.float32, device=self.device)
+      aux = torch.empty(B, dtype=pts.dtype, device=self.device)
     if B > 0:
       with torch.cuda.device(self.device):
         _capi.check(fn(self._h, pts.data_ptr(), c.data_ptr(), c_block,
@@ -158,29 +163,31 @@ class FlowEngine:
   # -- the C ABI, on tensors -------------------------------------------------
   def forward_logdet(self, x, cond, want_logdet=True):
     """base -> data: (y [B,D], log|det J| [B])."""
-    x = self._points(x, "forward")
+    x = self._points(x, "forward", keep_f64=True)
     return self._run(self.lib.cnf_forward_logdet, "cnf_forward_logdet", x, cond, True, want_logdet)
 
   def inverse_logdet(self, y, cond, want_logdet=True):
     """data -> base: (x [B,D], log|det J^-1| [B])."""
-    y = self._points(y, "inverse")
+    y = self._points(y, "inverse", keep_f64=True)
     return self._run(self.lib.cnf_inverse_logdet, "cnf_inverse_logdet", y, cond, True, want_logdet)
 
   def log_prob(self, value, cond) -> torch.Tensor:
-    value = self._points(value, "log_prob")
+    value = self._points(value, "log_prob", keep_f64=True)
     B = value.shape[0]
-    c, c_block = self.cond(cond, B)
-    lp = torch.empty(B, dtype=torch.float32, device=self.device)
+    f64 = value.dtype == torch.float64
+    c, c_block = self.cond(cond, B, value.dtype)
+    lp = torch.empty(B, dtype=value.dtype, device=self.device)
     if B > 0:
+      fn = self.lib.cnf_log_prob_f64 if f64 else self.lib.cnf_log_prob
       with torch.cuda.device(self.device):
-        _capi.check(self.lib.cnf_log_prob(self._h, value.data_ptr(), c.data_ptr(), c_block,
-                                          lp.data_ptr(), B, _stream_ptr(self.device)), "cnf_log_prob")
+        _capi.check(fn(self._h, value.data_ptr(), c.data_ptr(), c_block, lp.data_ptr(), B,
+                       _stream_ptr(self.device)), "cnf_log_prob")
     return lp
 
   def sample_logprob(self, noise, cond, want_logp=True, out=None, logp_out=None):
     """(samples [B,D], log_prob [B]) from base noise [B,D].  `out` / `logp_out`
     are optional preallocated result tensors (no allocation on the call)."""
-    noise = self._points(noise, "sample")
+    noise = self._points(noise, "sample", keep_f64=True)
     return self._run(self.lib.cnf_sample_logprob, "cnf_sample_logprob", noise, cond, True, want_logp,
                      out=out, aux=logp_out)
 

@@ -116,6 +116,24 @@ int cnf_sample_logprob(CnfModel *m, const float *noise, const float *c,
                        int64_t c_block, float *y, float *logp, int64_t B,
                        void *stream);
 
+/* float64 instantiation of the four functions above: the reference computes in
+ * float64 (jax.config.update("jax_enable_x64", True), solvers.py:23).  Double
+ * IO, double spline table and constants, ocml math, one sample per lane:
+ * agrees with a float64 evaluation of the reference algorithm to ~1e-12, at a
+ * fraction of the fp32 kernels' speed.  The parameters are the float32 vector
+ * given to cnf_model_set_params (each weight is widened exactly). */
+int cnf_forward_logdet_f64(CnfModel *m, const double *x, const double *c,
+                           int64_t c_block, double *y, double *logdet, int64_t B,
+                           void *stream);
+int cnf_inverse_logdet_f64(CnfModel *m, const double *y, const double *c,
+                           int64_t c_block, double *x, double *logdet, int64_t B,
+                           void *stream);
+int cnf_log_prob_f64(CnfModel *m, const double *value, const double *c,
+                     int64_t c_block, double *logp, int64_t B, void *stream);
+int cnf_sample_logprob_f64(CnfModel *m, const double *noise, const double *c,
+                           int64_t c_block, double *y, double *logp, int64_t B,
+                           void *stream);
+
 /* Replaces: the base draw `Independent(Normal(0,1)).sample(seed=rng, B)`
  * (conditional.py:378,399).  JAX's threefry stream cannot be reproduced
  * (JAX absent, stream version-dependent); the build's stream is

@@ -31,19 +31,21 @@ def dev():
   return torch.device("cuda", 0)
 
 
-def _fd_grad(fn, params64):
-  """(reference gradient at h = 1e-7, mask of entries where h = 1e-6 agrees)."""
+def _fd_grad(fn, params64, idx):
+  """(reference gradient at h = 1e-7 on the entries `idx`, mask of entries where h = 1e-6 agrees)."""
   out = []
   for h in (1e-7, 1e-6):
     g = np.zeros_like(params64)
-    for i in range(params64.size):
+    for i in idx:
       p = params64.copy(); p[i] += h
       fp = fn(p)
       p[i] -= 2 * h
       g[i] = (fp - fn(p)) / (2 * h)
     out.append(g)
   scale = max(np.abs(out[0]).max(), 1e-30)
-  return out[0], np.abs(out[0] - out[1]) <= 1e-5 * scale
+  ok = np.zeros(params64.size, dtype=bool)
+  ok[idx] = (np.abs(out[0] - out[1]) <= 1e-5 * scale)[idx]
+  return out[0], ok
 
 
 def _run(dev, D, kind_spec, B, n_slices, shared, scale_params, seed, rtol, name):
@@ -67,13 +69,19 @@ def _run(dev, D, kind_spec, B, n_slices, shared, scale_params, seed, rtol, name)
   pts64 = pts.cpu()
   p64 = params.flat.cpu().double().numpy()
   f = lambda p: float(OracleBackend(cfg, p).loss_terms(kind_spec, pts64, t, B, shared).sum())
-  g_fd, smooth = _fd_grad(f, p64)
+  # the 16 parameters of the shared `first` spline + a random 15 % of the conditioner weights
+  # (every tensor of every conditioner is hit; the full set takes minutes of CPU oracle time)
+  rs = np.random.default_rng(seed)
+  idx = np.concatenate([np.arange(16), 16 + rs.choice(p64.size - 16, max(1, (p64.size - 16) * 15 // 100), replace=False)]) \
+    if p64.size > 16 else np.arange(p64.size)
+  g_fd, smooth = _fd_grad(f, p64, idx)
   g = grad.cpu().double().numpy()
+  n_kink = int(idx.size - smooth.sum())
   err = np.abs(g - g_fd)[smooth].max() / max(np.abs(g_fd).max(), 1e-30)
   first_err = np.abs(g[:16] - g_fd[:16]).max() / max(np.abs(g_fd[:16]).max(), 1e-30)
   print(f"[grad {name} D={D}] |g|inf={np.abs(g_fd).max():.4g} rel err={err:.2e} (first-spline block {first_err:.2e}; "
-        f"{int((~smooth).sum())} of {g.size} entries at a kink excluded)")
-  assert (~smooth).sum() <= 0.02 * g.size
+        f"{n_kink} of {idx.size} checked entries at a kink excluded)")
+  assert n_kink <= 0.02 * idx.size + 1
   assert err <= rtol, (name, err)
   return g, g_fd
 

@@ -310,3 +310,31 @@ def test_wide_event_dimension(dev):
       assert _err(y, y_ref).max() <= TOL_Y and _err(lp, lp_ref).max() <= 5e-5
     xb, _ = eng.inverse_logdet(y, torch.tensor([0.4], device=dev))
     assert (xb.cpu() - torch.from_numpy(noise)).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN) + ["flow_d2_wild.npz"])
+def test_float64_kernels_match_oracle_to_1e12(golden_dir, dev, name):
+  """The float64 instantiation (the reference's dtype, solvers.py:23): every
+  golden vector, including the ill-conditioned scale-0.5 `wild` set, to
+  float64 round-off."""
+  kw = GOLDEN.get(name, dict(D=2))
+  fcfg, _ = _cfg_pair(**kw)
+  g = np.load(os.path.join(golden_dir, name))
+  eng = _engine(fcfg, g["params"], dev)
+  d64 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64)).to(dev)
+  # the wild set has local slopes up to e^16 per layer: two float64 evaluations that differ by one
+  # ulp in an intermediate (ocml vs glibc exp, fma contraction) land 1e-5 apart on its worst samples
+  tol = 1e-11 if "wild" not in name else 1e-4
+  worst = 0.0
+  for tag, c in (("u", g["c_uniform"]), ("p", g["c_per"])):
+    y, fldj = eng.forward_logdet(d64(g["noise"]), d64(c))
+    assert y.dtype == torch.float64
+    _, lp = eng.sample_logprob(d64(g["noise"]), d64(c))
+    xb, ildj = eng.inverse_logdet(d64(g[f"y_{tag}"]), d64(c))
+    lpd = eng.log_prob(d64(g[f"y_{tag}"]), d64(c))
+    for got, want in ((y, g[f"y_{tag}"]), (fldj, g[f"fldj_{tag}"]), (lp, g[f"lp_sample_{tag}"]),
+                      (xb, g[f"x_back_{tag}"]), (ildj, g[f"ildj_{tag}"]), (lpd, g[f"lp_{tag}"])):
+      e = np.abs(got.cpu().numpy() - want) / np.maximum(1.0, np.abs(want))
+      worst = max(worst, e.max())
+  print(f"\n[f64 {name}] worst relative-or-absolute error {worst:.2e}")
+  assert worst <= tol
