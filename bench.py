@@ -15,7 +15,7 @@ N GPUs : one process per GPU (torch.distributed, backend nccl = RCCL); every
          step's batch is sample-sharded in contiguous blocks of 65536/N
          (SURVEY.md 8e); no data-path collective; total work fixed => "strong".
 
-  python bench.py --gpus 1 --steps 4096 --warmup 256
+  python bench.py --gpus 1 --steps 16384 --warmup 1024
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -45,8 +45,8 @@ PEAK_HBM_GBS = 8000.0
 def parse_args():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=4096)
-  ap.add_argument("--warmup", type=int, default=256)
+  ap.add_argument("--steps", type=int, default=16384)
+  ap.add_argument("--warmup", type=int, default=1024)
   ap.add_argument("--slices-per-launch", type=int, default=256)
   ap.add_argument("--param-scale", type=float, default=0.2)
   ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,7 +184,7 @@ def main():
     "roofline": {
       "bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
       "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": None,
-      "kernel": "flow_kernel<16,5,to_base=false,fast>", "launch_ms": k_dur * 1e3,
+      "kernel": "cnf::flow_kernel<16,5,false,true,v2f,false> (packed fp32 VALU, 2 samples/lane)", "launch_ms": k_dur * 1e3,
       "samples_per_launch": k_samples, "flop_per_sample": FLOP_PER_SAMPLE,
       "note": "fp32 ALU bound: fp32 vector peak == fp32 MFMA peak (157.3 TFLOP/s) on gfx950; "
               "HBM view: %.1f GB/s of %.0f (%.3f)" % (achieved_gbs, PEAK_HBM_GBS, achieved_gbs / PEAK_HBM_GBS),

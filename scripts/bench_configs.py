@@ -69,3 +69,14 @@ entry("train_step_ot_batch2048", timeit(step, n=20), 2 * 2048 + 64 * 2, "update(
 
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/configs.json", "w"), indent=1)
+
+# float64 instantiation (exact mode) vs the fp32 default, same 4M samples
+be = model.terms_backend(params)
+n = 1 << 22
+z32 = be.normal(1, n); z64 = z32.double(); c32 = torch.tensor([0.5], device=dev); c64 = c32.double()
+y32 = torch.empty_like(z32); l32 = torch.empty(n, device=dev)
+t32 = timeit(lambda: be.sample_logprob(z32, c32, out=y32, logp_out=l32))
+t64 = timeit(lambda: be.sample_logprob(z64, c64))
+entry("sample_logprob_fp32_4M", t32, n, "default kernel")
+entry("sample_logprob_fp64_4M", t64, n, "float64 instantiation (exact mode)")
+json.dump(out, open("gpurun_out/configs.json", "w"), indent=1)
