@@ -56,28 +56,35 @@ __device__ __forceinline__ int64_t cond_prefix(int d) {      // floats of condit
 
 // forward of one pass with every layer input kept: St[s] is the input of step s
 // (St[0] filled by the caller), St[L] the result.  Returns the log-det sum.
-template <bool TO_BASE, bool FAST>
-__device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, const float* tab, float* St, float c) {
-  constexpr bool INV = !TO_BASE;
+// The direction is a RUNTIME (wave-uniform) flag and every pass of the kernel
+// goes through the single call site of this function and of pass_bwd: the
+// conditioner code (the bulk) exists once, so the kernel fits the instruction
+// cache (the first version inlined 10 forward + 6 backward copies: 34 k
+// instructions, 4x the cache).
+template <bool FAST>
+__device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, const float* tab, float* St, float c,
+                                                bool to_base) {
   const int D = a.D;
   uniform_ptr weights = as_uniform(a.prep + hdr_floats(GK));
   float acc = 0.0f;
   for (int s = 0; s < a.L; ++s) {
-    const int l = TO_BASE ? a.L - 1 - s : s;
+    const int l = to_base ? a.L - 1 - s : s;
     const bool odd = l & 1;
     const int first_idx = odd ? D - 1 : 0, idx_step = odd ? -1 : 1;
     const float* cu = St + s * D * GTS + threadIdx.x;
     float* co = St + (s + 1) * D * GTS + threadIdx.x;
     float o, ld;
-    table_spline<GK, INV, FAST, float>(tab, cu[first_idx * GTS], a.sc, o, ld);
+    if (to_base) table_spline<GK, false, FAST, float>(tab, cu[first_idx * GTS], a.sc, o, ld);
+    else table_spline<GK, true, FAST, float>(tab, cu[first_idx * GTS], a.sc, o, ld);
     co[first_idx * GTS] = o;
     acc += ld;
     uniform_ptr w = weights + l * a.per_layer;
     for (int d = 1; d < D; ++d) {
       const int i = first_idx + d * idx_step;
       float th[GP];
-      conditioner<16, GP, float>(w, d, 2, c, TO_BASE ? co : cu, first_idx, idx_step, GTS, th);
-      cond_spline<GK, INV, FAST, float>(th, cu[i * GTS], a.sc, o, ld);
+      conditioner<16, GP, float>(w, d, 2, c, to_base ? co : cu, first_idx, idx_step, GTS, th);
+      if (to_base) cond_spline<GK, false, FAST, float>(th, cu[i * GTS], a.sc, o, ld);
+      else cond_spline<GK, true, FAST, float>(th, cu[i * GTS], a.sc, o, ld);
       co[i * GTS] = o;
       acc += ld;
       w += cond_floats(d, 16, 2, GP);
@@ -87,19 +94,18 @@ __device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, const float*
 }
 
 // backward of the pass whose stash is in St.  Aa holds the adjoint of the final
-// output on entry and the adjoint of the pass input on exit (the function
-// ping-pongs between Aa and Ab and returns the buffer that holds the result).
-template <bool TO_BASE, bool FAST>
+// output on entry; the function ping-pongs between Aa and Ab and returns the
+// buffer that holds the adjoint of the pass input.
+template <bool FAST>
 __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab, const float* St, float* Aa,
-                                           float* Ab, float ld_bar, float c, float* gslab, float* stage,
-                                           FirstAcc& fa) {
-  constexpr bool INV = !TO_BASE;
+                                           float* Ab, float ld_bar, float c, bool to_base, float* gslab,
+                                           float* stage, FirstAcc& fa) {
   const int D = a.D;
   uniform_ptr weights = as_uniform(a.prep + hdr_floats(GK));
   float* Ao = Aa;
   float* Au = Ab;
   for (int s = a.L - 1; s >= 0; --s) {
-    const int l = TO_BASE ? a.L - 1 - s : s;
+    const int l = to_base ? a.L - 1 - s : s;
     const bool odd = l & 1;
     const int first_idx = odd ? D - 1 : 0, idx_step = odd ? -1 : 1;
     const float* cu = St + s * D * GTS + threadIdx.x;
@@ -113,14 +119,20 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab,
       const int i = first_idx + d * idx_step;
       uniform_ptr w = weights + l * a.per_layer + off;
       float h1[16], h2[16], th[GP], tb[GP];
-      conditioner_keep(w, d, c, TO_BASE ? co : cu, first_idx, idx_step, GTS, h1, h2, th);
-      const float vb = cond_spline_bwd<GK, INV, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
+      conditioner_keep(w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, h1, h2, th);
+      float vb;
+      if (to_base) vb = cond_spline_bwd<GK, false, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
+      else vb = cond_spline_bwd<GK, true, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
       au[i * GTS] += vb;
-      conditioner_bwd(w, d, c, TO_BASE ? co : cu, first_idx, idx_step, GTS, h1, h2, tb, TO_BASE ? ao : au,
+      conditioner_bwd(w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, h1, h2, tb, to_base ? ao : au,
                       gslab + GP + l * a.per_layer + off, stage);
     }
-    au[first_idx * GTS] += table_spline_bwd<GK, INV>(tab, cu[first_idx * GTS], co[first_idx * GTS],
-                                                      ao[first_idx * GTS], ld_bar, a.sc, fa.Wb, fa.Hb, fa.Db);
+    float vb0;
+    if (to_base) vb0 = table_spline_bwd<GK, false>(tab, cu[first_idx * GTS], co[first_idx * GTS], ao[first_idx * GTS],
+                                                   ld_bar, a.sc, fa.Wb, fa.Hb, fa.Db);
+    else vb0 = table_spline_bwd<GK, true>(tab, cu[first_idx * GTS], co[first_idx * GTS], ao[first_idx * GTS],
+                                          ld_bar, a.sc, fa.Wb, fa.Hb, fa.Db);
+    au[first_idx * GTS] += vb0;
     float* t = Ao; Ao = Au; Au = t;
   }
   return Ao;
@@ -129,7 +141,7 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab,
 __device__ __forceinline__ float base_lp(const float* col, int D) {
   float b = 0.0f;
   for (int d = 0; d < D; ++d) { const float x = col[d * GTS]; b = fmaf(-0.5f * x, x, b); }
-  return b - D * HALF_LOG_2PI;
+  return b - (float)(D * HALF_LOG_2PI);
 }
 
 // R3b[e] -= sum_d ubar_d * d drift_d / d r_e   (flow_matching_loss_fn's target field)
@@ -159,6 +171,19 @@ __device__ __forceinline__ void drift_vjp(const float* r3, const float* ub, floa
   }
 }
 
+// Roles of the steps of a tile's pass program.  Every step is: build the pass
+// input, run the forward with stash, act on its result, optionally seed and run
+// the backward, act on the input adjoint.
+enum Role {
+  R_NEG,          // -log_prob of the points (data -> base)
+  R_POT, R_RKL,   // potential / reverse KL (base -> data)
+  R_R1, R_R2,     // finite-difference velocity: r1 kept, then velocity formed
+  R_R3,           // sample at t for the score terms
+  R_LPP, R_LPM,   // log_prob at r3 +- dx/2 e_d (forward only / forward + backward of the minus pass)
+  R_LPPB,         // the plus pass again, with backward
+  R_R3B, R_R2B, R_R1B   // backward of r3 / r2 / r1 (forward recomputed)
+};
+
 template <bool FAST>
 __global__ __launch_bounds__(TILE, 1) void grad_kernel(const GradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -185,6 +210,11 @@ __global__ __launch_bounds__(TILE, 1) void grad_kernel(const GradArgs a) {
 #pragma unroll
   for (int j = 0; j <= GK; ++j) fa.Db[j] = 0.0f;
 
+  const float dt = a.spec.dt, dx = a.spec.dx, coef = a.spec.coef;
+  const bool score = kind == CNF_TERM_KINETIC_SCORE || kind == CNF_TERM_FLOW_MATCHING;
+  // number of steps of the pass program
+  const int n_steps = kind == CNF_TERM_KINETIC ? 3 : (score ? 3 + 3 * D + 3 : 1);
+
   const int64_t tiles_per_slice = (a.B + GTS - 1) / GTS;
   const int64_t n_tiles = tiles_per_slice * a.n_slices;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -200,111 +230,141 @@ __global__ __launch_bounds__(TILE, 1) void grad_kernel(const GradArgs a) {
     float* s0 = St + tid;               // stash 0 column
     float* sL = St + L * DT + tid;      // final output column
     float* aa = Aa + tid;
-    float lossv = 0.0f;
+    float* v_ = V + tid;
+    float* r3 = R3 + tid;
+    float* r3b = R3b + tid;
+    float* ub = Ub + tid;
+    float lossv = 0.0f, lp_plus = 0.0f, ubar = 0.0f;
 
-    if (kind == CNF_TERM_NEG_LOGPROB) {
-      for (int d = 0; d < D; ++d) s0[d * GTS] = n_[d * GTS];
-      const float ildj = pass_fwd_stash<true, FAST>(a.m, tab, St, t);
-      lossv = -(base_lp(sL, D) + ildj);
-      for (int d = 0; d < D; ++d) aa[d * GTS] = sc * sL[d * GTS];      // d(-lp)/dx_d = x_d
-      pass_bwd<true, FAST>(a.m, tab, St, Aa, Ab, -sc, t, gslab, stage, fa);
-    } else if (kind == CNF_TERM_POTENTIAL || kind == CNF_TERM_REVERSE_KL) {
-      for (int d = 0; d < D; ++d) s0[d * GTS] = n_[d * GTS];
-      const float fldj = pass_fwd_stash<false, FAST>(a.m, tab, St, t);
+    for (int st = 0; st < n_steps; ++st) {
+      // ---- decode the step
+      int role, dd = 0;
+      if (kind == CNF_TERM_NEG_LOGPROB) role = R_NEG;
+      else if (kind == CNF_TERM_POTENTIAL) role = R_POT;
+      else if (kind == CNF_TERM_REVERSE_KL) role = R_RKL;
+      else if (kind == CNF_TERM_KINETIC) role = st == 0 ? R_R1 : (st == 1 ? R_R2 : R_R1B);
+      else {
+        if (st < 3) role = st == 0 ? R_R1 : (st == 1 ? R_R2 : R_R3);
+        else if (st < 3 + 3 * D) { dd = (st - 3) / 3; const int q = (st - 3) - 3 * dd; role = q == 0 ? R_LPP : (q == 1 ? R_LPM : R_LPPB); }
+        else { const int q = st - (3 + 3 * D); role = q == 0 ? R_R3B : (q == 1 ? R_R2B : R_R1B); }
+      }
+      const bool to_base = role == R_NEG || role == R_LPP || role == R_LPM || role == R_LPPB;
+      const float c = (role == R_R1 || role == R_R1B) ? t - 0.5f * dt
+                    : ((role == R_R2 || role == R_R2B) ? t + 0.5f * dt : t);
+      // ---- pass input
+      if (role == R_LPP || role == R_LPM || role == R_LPPB) {
+        for (int e = 0; e < D; ++e) s0[e * GTS] = r3[e * GTS];
+        s0[dd * GTS] += role == R_LPM ? -0.5f * dx : 0.5f * dx;
+      } else {
+        for (int e = 0; e < D; ++e) s0[e * GTS] = n_[e * GTS];
+      }
+      const float ldsum = pass_fwd_stash<FAST>(a.m, tab, St, c, to_base);
+      // ---- act on the result, prepare the seeds
+      bool do_bwd = false;
       float ld_bar = 0.0f;
-      if (kind == CNF_TERM_POTENTIAL) {
-        const float pa = a.spec.a;
-        if (a.spec.subtype == CNF_POT_DOUBLE_WELL) {
-          float sm = 0.0f, sp = 0.0f;
-          for (int d = 0; d < D; ++d) { const float r = sL[d * GTS]; sm = fmaf(r - pa, r - pa, sm); sp = fmaf(r + pa, r + pa, sp); }
-          lossv = sm * sp * 0.25f;
-          for (int d = 0; d < D; ++d) { const float r = sL[d * GTS]; aa[d * GTS] = sc * 0.5f * ((r - pa) * sp + (r + pa) * sm); }
-        } else {
-          float s2 = 0.0f;
-          for (int d = 0; d < D; ++d) { const float r = sL[d * GTS]; s2 = fmaf(r, r, s2); }
-          if (a.spec.subtype == CNF_POT_OBSTACLE) {
-            lossv = 50.0f * expf(-0.5f * s2);
-            for (int d = 0; d < D; ++d) aa[d * GTS] = -sc * lossv * sL[d * GTS];
+      switch (role) {
+        case R_NEG: {
+          lossv = -(base_lp(sL, D) + ldsum);
+          for (int e = 0; e < D; ++e) aa[e * GTS] = sc * sL[e * GTS];      // d(-lp)/dx_e = x_e
+          ld_bar = -sc; do_bwd = true;
+          break;
+        }
+        case R_POT: {
+          const float pa = a.spec.a;
+          if (a.spec.subtype == CNF_POT_DOUBLE_WELL) {
+            float sm = 0.0f, sp = 0.0f;
+            for (int e = 0; e < D; ++e) { const float r = sL[e * GTS]; sm = fmaf(r - pa, r - pa, sm); sp = fmaf(r + pa, r + pa, sp); }
+            lossv = sm * sp * 0.25f;
+            for (int e = 0; e < D; ++e) { const float r = sL[e * GTS]; aa[e * GTS] = sc * 0.5f * ((r - pa) * sp + (r + pa) * sm); }
           } else {
-            lossv = 0.5f * s2;
-            for (int d = 0; d < D; ++d) aa[d * GTS] = sc * sL[d * GTS];
-          }
-        }
-      } else {
-        const float lp = base_lp(n_, D) - fldj;
-        float s2 = 0.0f;
-        for (int d = 0; d < D; ++d) { const float r = sL[d * GTS]; s2 = fmaf(r, r, s2); }
-        const float Tt = a.spec.T, vs = 2.0f / a.spec.beta * (Tt + 1.0f), vt = 2.0f / a.spec.beta;
-        const float ws = (Tt - t) / Tt, wt = t / Tt;
-        const float ls = -0.5f * D * logf(6.283185307179586f * vs), lt = -0.5f * D * logf(6.283185307179586f * vt);
-        const float as = -0.5f * s2 / vs + ls, at = -0.5f * s2 / vt + lt;
-        const float mx = fmaxf(as, at);
-        const float es = expf(as - mx) * ws, et = expf(at - mx) * wt;
-        lossv = lp - (mx + logf(es + et));
-        // d logmix / d y_d = -y_d (es/vs + et/vt) / (es + et)
-        const float g = (es / vs + et / vt) / (es + et);
-        for (int d = 0; d < D; ++d) aa[d * GTS] = sc * g * sL[d * GTS];
-        ld_bar = -sc;
-      }
-      pass_bwd<false, FAST>(a.m, tab, St, Aa, Ab, ld_bar, t, gslab, stage, fa);
-    } else {
-      const float dt = a.spec.dt, inv_dt = 1.0f / dt;
-      float* v_ = V + tid;
-      for (int d = 0; d < D; ++d) s0[d * GTS] = n_[d * GTS];
-      pass_fwd_stash<false, FAST>(a.m, tab, St, t - 0.5f * dt);
-      for (int d = 0; d < D; ++d) v_[d * GTS] = sL[d * GTS];
-      pass_fwd_stash<false, FAST>(a.m, tab, St, t + 0.5f * dt);          // stash now holds the r2 pass
-      for (int d = 0; d < D; ++d) v_[d * GTS] = (sL[d * GTS] - v_[d * GTS]) * inv_dt;
-      float* ub = Ub + tid;
-      if (kind == CNF_TERM_KINETIC) {
-        for (int d = 0; d < D; ++d) { const float v = v_[d * GTS]; lossv = fmaf(v, v, lossv); ub[d * GTS] = 2.0f * sc * v; }
-      } else {
-        const float dx = a.spec.dx, coef = a.spec.coef;
-        float* r3 = R3 + tid;
-        float* r3b = R3b + tid;
-        pass_fwd_stash<false, FAST>(a.m, tab, St, t);
-        for (int d = 0; d < D; ++d) { r3[d * GTS] = sL[d * GTS]; r3b[d * GTS] = 0.0f; }
-        for (int d = 0; d < D; ++d) {
-          float lp[2];
-          for (int sg = 0; sg < 2; ++sg) {                               // + then -: the stash ends on the - pass
-            for (int e = 0; e < D; ++e) s0[e * GTS] = r3[e * GTS];
-            s0[d * GTS] += sg == 0 ? 0.5f * dx : -0.5f * dx;
-            const float ildj = pass_fwd_stash<true, FAST>(a.m, tab, St, t);
-            lp[sg] = base_lp(sL, D) + ildj;
-          }
-          float u = fmaf((lp[0] - lp[1]) / dx, coef, v_[d * GTS]);
-          if (kind == CNF_TERM_FLOW_MATCHING) u -= drift_of<float>(r3, d, D, GTS, a.spec.subtype, a.spec.a);
-          lossv = fmaf(u, u, lossv);
-          const float ubar = 2.0f * sc * u;
-          ub[d * GTS] = ubar;
-          for (int sg = 1; sg >= 0; --sg) {                              // - first (its stash is live), then +
-            const float lp_bar = (sg == 0 ? ubar : -ubar) * coef / dx;
-            if (sg == 0) {
-              for (int e = 0; e < D; ++e) s0[e * GTS] = r3[e * GTS];
-              s0[d * GTS] += 0.5f * dx;
-              pass_fwd_stash<true, FAST>(a.m, tab, St, t);
+            float s2 = 0.0f;
+            for (int e = 0; e < D; ++e) { const float r = sL[e * GTS]; s2 = fmaf(r, r, s2); }
+            if (a.spec.subtype == CNF_POT_OBSTACLE) {
+              lossv = 50.0f * expf(-0.5f * s2);
+              for (int e = 0; e < D; ++e) aa[e * GTS] = -sc * lossv * sL[e * GTS];
+            } else {
+              lossv = 0.5f * s2;
+              for (int e = 0; e < D; ++e) aa[e * GTS] = sc * sL[e * GTS];
             }
-            for (int e = 0; e < D; ++e) aa[e * GTS] = -lp_bar * sL[e * GTS];   // d base / d x_e = -x_e
-            const float* ain = pass_bwd<true, FAST>(a.m, tab, St, Aa, Ab, lp_bar, t, gslab, stage, fa) + tid;
-            for (int e = 0; e < D; ++e) r3b[e * GTS] += ain[e * GTS];
           }
+          do_bwd = true;
+          break;
         }
-        if (kind == CNF_TERM_FLOW_MATCHING) drift_vjp(r3, ub, r3b, D, a.spec.subtype, a.spec.a);
-        // r3 pass
-        for (int d = 0; d < D; ++d) s0[d * GTS] = n_[d * GTS];
-        pass_fwd_stash<false, FAST>(a.m, tab, St, t);
-        for (int d = 0; d < D; ++d) aa[d * GTS] = r3b[d * GTS];
-        pass_bwd<false, FAST>(a.m, tab, St, Aa, Ab, 0.0f, t, gslab, stage, fa);
-        // r2 pass (re-run: its stash was overwritten)
-        for (int d = 0; d < D; ++d) s0[d * GTS] = n_[d * GTS];
-        pass_fwd_stash<false, FAST>(a.m, tab, St, t + 0.5f * dt);
+        case R_RKL: {
+          const float lp = base_lp(n_, D) - ldsum;
+          float s2 = 0.0f;
+          for (int e = 0; e < D; ++e) { const float r = sL[e * GTS]; s2 = fmaf(r, r, s2); }
+          const float Tt = a.spec.T, vs = 2.0f / a.spec.beta * (Tt + 1.0f), vt = 2.0f / a.spec.beta;
+          const float ws = (Tt - t) / Tt, wt = t / Tt;
+          const float ls = -0.5f * D * logf(6.283185307179586f * vs), lt = -0.5f * D * logf(6.283185307179586f * vt);
+          const float as = -0.5f * s2 / vs + ls, at = -0.5f * s2 / vt + lt;
+          const float mx = fmaxf(as, at);
+          const float es = expf(as - mx) * ws, et = expf(at - mx) * wt;
+          lossv = lp - (mx + logf(es + et));
+          const float g = (es / vs + et / vt) / (es + et);      // -d logmix / d y_e = g * y_e
+          for (int e = 0; e < D; ++e) aa[e * GTS] = sc * g * sL[e * GTS];
+          ld_bar = -sc; do_bwd = true;
+          break;
+        }
+        case R_R1:
+          for (int e = 0; e < D; ++e) v_[e * GTS] = sL[e * GTS];
+          break;
+        case R_R2: {
+          const float inv_dt = 1.0f / dt;
+          for (int e = 0; e < D; ++e) v_[e * GTS] = (sL[e * GTS] - v_[e * GTS]) * inv_dt;      // velocity
+          if (kind == CNF_TERM_KINETIC) {
+            for (int e = 0; e < D; ++e) {
+              const float v = v_[e * GTS];
+              lossv = fmaf(v, v, lossv);
+              ub[e * GTS] = 2.0f * sc * v;
+              aa[e * GTS] = ub[e * GTS] * inv_dt;
+            }
+            do_bwd = true;                          // the r2 stash is live
+          }
+          break;
+        }
+        case R_R3:
+          for (int e = 0; e < D; ++e) { r3[e * GTS] = sL[e * GTS]; r3b[e * GTS] = 0.0f; }
+          break;
+        case R_LPP:
+          lp_plus = base_lp(sL, D) + ldsum;
+          break;
+        case R_LPM: {
+          const float lp_minus = base_lp(sL, D) + ldsum;
+          float u = fmaf((lp_plus - lp_minus) / dx, coef, v_[dd * GTS]);
+          if (kind == CNF_TERM_FLOW_MATCHING) u -= drift_of<float>(r3, dd, D, GTS, a.spec.subtype, a.spec.a);
+          lossv = fmaf(u, u, lossv);
+          ubar = 2.0f * sc * u;
+          ub[dd * GTS] = ubar;
+          ld_bar = -ubar * coef / dx;                // d u / d lp_minus
+          for (int e = 0; e < D; ++e) aa[e * GTS] = -ld_bar * sL[e * GTS];     // d base / d x_e = -x_e
+          do_bwd = true;
+          break;
+        }
+        case R_LPPB:
+          ld_bar = ubar * coef / dx;
+          for (int e = 0; e < D; ++e) aa[e * GTS] = -ld_bar * sL[e * GTS];
+          do_bwd = true;
+          break;
+        case R_R3B:
+          if (kind == CNF_TERM_FLOW_MATCHING) drift_vjp(r3, ub, r3b, D, a.spec.subtype, a.spec.a);
+          for (int e = 0; e < D; ++e) aa[e * GTS] = r3b[e * GTS];
+          do_bwd = true;
+          break;
+        case R_R2B:
+          for (int e = 0; e < D; ++e) aa[e * GTS] = ub[e * GTS] / dt;
+          do_bwd = true;
+          break;
+        default:   // R_R1B
+          for (int e = 0; e < D; ++e) aa[e * GTS] = -ub[e * GTS] / dt;
+          do_bwd = true;
+          break;
       }
-      for (int d = 0; d < D; ++d) aa[d * GTS] = ub[d * GTS] * inv_dt;
-      pass_bwd<false, FAST>(a.m, tab, St, Aa, Ab, 0.0f, t + 0.5f * dt, gslab, stage, fa);
-      for (int d = 0; d < D; ++d) s0[d * GTS] = n_[d * GTS];
-      pass_fwd_stash<false, FAST>(a.m, tab, St, t - 0.5f * dt);
-      for (int d = 0; d < D; ++d) aa[d * GTS] = -ub[d * GTS] * inv_dt;
-      pass_bwd<false, FAST>(a.m, tab, St, Aa, Ab, 0.0f, t - 0.5f * dt, gslab, stage, fa);
+      if (do_bwd) {
+        const float* ain = pass_bwd<FAST>(a.m, tab, St, Aa, Ab, ld_bar, c, to_base, gslab, stage, fa) + tid;
+        if (role == R_LPM || role == R_LPPB)
+          for (int e = 0; e < D; ++e) r3b[e * GTS] += ain[e * GTS];
+      }
     }
     float part = valid ? lossv : 0.0f;
 #pragma unroll
@@ -330,36 +390,51 @@ __global__ __launch_bounds__(TILE, 1) void grad_kernel(const GradArgs a) {
 
 // grad[p] += sum over slabs; the first 16 entries are per-bin adjoint sums of
 // the `first` spline and go through the softmax / softplus Jacobians (float64).
-__global__ void grad_finish_kernel(const float* __restrict__ slabs, int64_t n_slabs, int64_t n_params,
-                                   const float* __restrict__ params, float* __restrict__ grad, double span_eff,
-                                   double sp_offset) {
+// Block = 32 parameters x 32 slab stripes (a thread that walks all slabs alone
+// pays one dependent L2 round trip per slab: 1-2 ms for 2 048 slabs).
+__global__ __launch_bounds__(1024) void grad_finish_kernel(const float* __restrict__ slabs, int64_t n_slabs,
+                                                           int64_t n_params, const float* __restrict__ params,
+                                                           float* __restrict__ grad, double span_eff,
+                                                           double sp_offset) {
+  __shared__ float part[32][33];
   __shared__ double raw[GP];
-  const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (blockIdx.x == 0 && threadIdx.x < GP) {
-    double s = 0.0;
-    for (int64_t b = 0; b < n_slabs; ++b) s += (double)slabs[b * n_params + threadIdx.x];
-    raw[threadIdx.x] = s;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t p = (int64_t)blockIdx.x * 32 + tx;
+  float acc = 0.0f;
+  if (p < n_params) {
+    int64_t b = ty;
+    for (; b + 96 < n_slabs; b += 128) {       // four independent loads in flight
+      const float v0 = slabs[b * n_params + p], v1 = slabs[(b + 32) * n_params + p];
+      const float v2 = slabs[(b + 64) * n_params + p], v3 = slabs[(b + 96) * n_params + p];
+      acc += (v0 + v1) + (v2 + v3);
+    }
+    for (; b < n_slabs; b += 32) acc += slabs[b * n_params + p];
+  }
+  part[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0) {
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) s += part[k][tx];
+    if (blockIdx.x == 0 && tx < GP) raw[tx] = (double)s;
+    else if (p < n_params) grad[p] += s;
   }
   __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x < GP) {
     const int j = threadIdx.x;
     double g;
     if (j < 2 * GK) {
-      const int part = j / GK, jj = j % GK;
-      double mx = params[part * GK];
-      for (int k = 1; k < GK; ++k) mx = fmax(mx, (double)params[part * GK + k]);
+      const int pt = j / GK, jj = j % GK;
+      double mx = params[pt * GK];
+      for (int k = 1; k < GK; ++k) mx = fmax(mx, (double)params[pt * GK + k]);
       double pr[GK], sum = 0.0, dot = 0.0;
-      for (int k = 0; k < GK; ++k) { pr[k] = exp((double)params[part * GK + k] - mx); sum += pr[k]; }
-      for (int k = 0; k < GK; ++k) { pr[k] /= sum; dot += raw[part * GK + k] * pr[k]; }
+      for (int k = 0; k < GK; ++k) { pr[k] = exp((double)params[pt * GK + k] - mx); sum += pr[k]; }
+      for (int k = 0; k < GK; ++k) { pr[k] /= sum; dot += raw[pt * GK + k] * pr[k]; }
       g = span_eff * pr[jj] * (raw[j] - dot);
     } else {
       g = raw[j] / (1.0 + exp(-((double)params[j] + sp_offset)));
     }
     grad[j] += (float)g;
-  } else if (p >= GP && p < n_params) {
-    float s = 0.0f;
-    for (int64_t b = 0; b < n_slabs; ++b) s += slabs[b * n_params + p];
-    grad[p] += s;
   }
 }
 
@@ -424,8 +499,8 @@ extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const f
     hipLaunchKernelGGL(grad_kernel<false>, dim3((unsigned)grid), dim3(TILE), lds, stream, a);
   }
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
-  const int fb = (int)((m->n_params + 255) / 256);
-  hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(256), 0, stream, m->grad_slabs, n_slabs, m->n_params, params,
+  const int fb = (int)((m->n_params + 31) / 32);
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, n_slabs, m->n_params, params,
                      grad, (double)m->sc.span_eff, (double)m->sc.sp_offset);
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
