@@ -12,6 +12,7 @@ names so JAX-trained parameters can be exported with
 ``np.savez(path, **{f"{mod}/{name}": arr for mod, d in params.items() for name, arr in d.items()})``.
 """
 from dataclasses import dataclass
+from functools import lru_cache
 from typing import Dict, Iterator, List, Tuple
 
 import numpy as np
@@ -37,9 +38,20 @@ class FlowConfig:
     return 3 * self.num_bins + 1
 
   def param_count(self) -> int:
-    return sum(int(np.prod(shape)) for _, _, shape in param_spec(self))
+    return _param_count(self)
 
 
+@lru_cache(maxsize=None)
+def _param_count(cfg: "FlowConfig") -> int:
+  return sum(n for _, _, _, n in _spec_sizes(cfg))
+
+
+@lru_cache(maxsize=None)
+def _spec_sizes(cfg: "FlowConfig"):
+  return tuple((m, n, s, int(np.prod(s))) for m, n, s in param_spec(cfg))
+
+
+@lru_cache(maxsize=None)
 def param_spec(cfg: FlowConfig) -> List[Tuple[str, str, Tuple[int, ...]]]:
   """(module, name, shape) in flat-layout order."""
   H, P = cfg.hidden_size, cfg.num_bijector_params
@@ -70,8 +82,7 @@ class Params(dict):
     self.cfg = cfg
     self.flat = flat
     off = 0
-    for mod, name, shape in param_spec(cfg):
-      n = int(np.prod(shape))
+    for mod, name, shape, n in _spec_sizes(cfg):
       self.setdefault(mod, {})[name] = flat[off:off + n].view(*shape)
       off += n
 
