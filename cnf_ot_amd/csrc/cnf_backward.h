@@ -297,6 +297,9 @@ __device__ __forceinline__ void wgrad_mfma(float* stage, const float (&a)[16], c
 // adjoints of the d conditioning inputs (accumulated into adj_col).
 // Lanes whose sample is beyond the batch must pass theta_bar = 0.
 // ---------------------------------------------------------------------------
+// WGRAD=false: only the adjoints of the conditioning inputs (vector-Jacobian
+// products w.r.t. the points: forward_jac / inverse_jac / gauge_potential).
+template <bool WGRAD = true>
 __device__ __forceinline__ void conditioner_bwd(uniform_ptr w, int d, float c, const float* col, int first_idx,
                                                 int idx_step, int stride, const float (&h1)[16],
                                                 const float (&h2)[16], const float (&tb)[16], float* adj_col,
@@ -304,32 +307,34 @@ __device__ __forceinline__ void conditioner_bwd(uniform_ptr w, int d, float c, c
   w = launder(w);
   const int o_b0 = (1 + d) * 16, o_w1 = o_b0 + 16, o_b1 = o_w1 + 256, o_wo = o_b1 + 16, o_bo = o_wo + 256;
   // output layer
-  wgrad_mfma(stage, h2, tb, gw + o_wo, 16, gw + o_bo);
+  if constexpr (WGRAD) wgrad_mfma(stage, h2, tb, gw + o_wo, 16, gw + o_bo);
   float g2[16];
   dense_T(w + o_wo, tb, g2);
 #pragma unroll
   for (int i = 0; i < 16; ++i) g2[i] = h2[i] > 0.0f ? g2[i] : 0.0f;
   materialize<16>(g2);
   // hidden layer
-  wgrad_mfma(stage, h1, g2, gw + o_w1, 16, gw + o_b1);
+  if constexpr (WGRAD) wgrad_mfma(stage, h1, g2, gw + o_w1, 16, gw + o_b1);
   float g1[16];
   dense_T(w + o_w1, g2, g1);
 #pragma unroll
   for (int i = 0; i < 16; ++i) g1[i] = h1[i] > 0.0f ? g1[i] : 0.0f;
   materialize<16>(g1);
   // first layer: inputs [c, v_0..v_{d-1}, 1] (the constant row yields the bias gradient)
-  float in[16];
+  if constexpr (WGRAD) {
+    float in[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) in[r] = 0.0f;
-  in[0] = c;
-  for (int q = 0; q < d && q < 14; ++q) {
-    const float v = col[(first_idx + q * idx_step) * stride];
+    for (int r = 0; r < 16; ++r) in[r] = 0.0f;
+    in[0] = c;
+    for (int q = 0; q < d && q < 14; ++q) {
+      const float v = col[(first_idx + q * idx_step) * stride];
 #pragma unroll
-    for (int r = 1; r < 15; ++r) in[r] = (r == q + 1) ? v : in[r];
+      for (int r = 1; r < 15; ++r) in[r] = (r == q + 1) ? v : in[r];
+    }
+#pragma unroll
+    for (int r = 1; r < 16; ++r) in[r] = (r == d + 1) ? 1.0f : in[r];
+    wgrad_mfma(stage, in, g1, gw, d + 2, nullptr);
   }
-#pragma unroll
-  for (int r = 1; r < 16; ++r) in[r] = (r == d + 1) ? 1.0f : in[r];
-  wgrad_mfma(stage, in, g1, gw, d + 2, nullptr);
   for (int q = 0; q < d; ++q) {          // adjoints of the conditioning inputs
     float wr[16];
     load_row<16>(w + (1 + q) * 16, wr);

@@ -96,7 +96,7 @@ __device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, const float*
 // backward of the pass whose stash is in St.  Aa holds the adjoint of the final
 // output on entry; the function ping-pongs between Aa and Ab and returns the
 // buffer that holds the adjoint of the pass input.
-template <bool FAST>
+template <bool FAST, bool WGRAD = true>
 __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab, const float* St, float* Aa,
                                            float* Ab, float ld_bar, float c, bool to_base, float* gslab,
                                            float* stage, FirstAcc& fa) {
@@ -124,8 +124,8 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab,
       if (to_base) vb = cond_spline_bwd<GK, false, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
       else vb = cond_spline_bwd<GK, true, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
       au[i * GTS] += vb;
-      conditioner_bwd(w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, h1, h2, tb, to_base ? ao : au,
-                      gslab + GP + l * a.per_layer + off, stage);
+      conditioner_bwd<WGRAD>(w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, h1, h2, tb, to_base ? ao : au,
+                             gslab + GP + l * a.per_layer + off, stage);
     }
     float vb0;
     if (to_base) vb0 = table_spline_bwd<GK, false>(tab, cu[first_idx * GTS], co[first_idx * GTS], ao[first_idx * GTS],
@@ -388,6 +388,65 @@ __global__ __launch_bounds__(TILE, 1) void grad_kernel(const GradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// vjp_kernel: vector-Jacobian product of ONE flow pass with respect to its
+// input points -- the building block of the reference's autodiff helpers
+// forward_jac / inverse_jac / gauge_potential (flows.py:203-211):
+//   xbar[b,:] = ybar[b,:] . dF/dx(b)  +  ldbar[b] * d logdet/dx(b)
+// Same forward-with-stash + backward as grad_kernel, without weight gradients.
+// ---------------------------------------------------------------------------
+struct VjpArgs {
+  ModelArgs m;
+  const float* pts;      // [B, D]
+  const float* c;
+  const float* ybar;     // [B, D] or null (= 0)
+  const float* ldbar;    // [B] or null (= 0)
+  float* xbar;           // [B, D]
+  int64_t B, c_block;
+  int32_t to_base;
+  uint32_t div_magic;
+};
+
+template <bool FAST>
+__global__ __launch_bounds__(TILE, 2) void vjp_kernel(const VjpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int HDR = hdr_floats(GK);
+  const int D = a.m.D, L = a.m.L, DT = D * GTS;
+  float* tab = lds;
+  float* St = lds + HDR;
+  float* Aa = St + (L + 1) * DT;
+  float* Ab = Aa + DT;
+  for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = a.m.prep[i];
+  const int tid = threadIdx.x;
+  FirstAcc fa;      // written, never read: removed by the compiler
+#pragma unroll
+  for (int j = 0; j < GK; ++j) { fa.Wb[j] = 0.0f; fa.Hb[j] = 0.0f; }
+#pragma unroll
+  for (int j = 0; j <= GK; ++j) fa.Db[j] = 0.0f;
+  const int64_t n_tiles = (a.B + GTS - 1) / GTS;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t tile_start = tile * GTS;
+    const int64_t i = tile_start + tid;
+    __syncthreads();
+    tile_load1(a.pts, St, D, a.div_magic, tile_start, a.B);
+    if (a.ybar) tile_load1(a.ybar, Aa, D, a.div_magic, tile_start, a.B);
+    else for (int e = tid; e < DT; e += TILE) Aa[e] = 0.0f;
+    const float c = i < a.B ? a.c[a.c_block >= a.B ? 0 : i / a.c_block] : 0.0f;
+    const float ld_bar = (a.ldbar && i < a.B) ? a.ldbar[i] : 0.0f;
+    __syncthreads();
+    pass_fwd_stash<FAST>(a.m, tab, St, c, a.to_base != 0);
+    float* ain = pass_bwd<FAST, false>(a.m, tab, St, Aa, Ab, ld_bar, c, a.to_base != 0, nullptr, nullptr, fa);
+    __syncthreads();
+    // coalesced store of the input adjoints
+    const int64_t base = tile_start * D;
+    const int n_el = (int)(a.B - tile_start < GTS ? a.B - tile_start : GTS) * D;
+    for (int e = tid; e < GTS * D; e += TILE) {
+      const int s = a.div_magic ? (int)__umulhi((uint32_t)e, a.div_magic) : e, d = e - s * D;
+      if (e < n_el) a.xbar[base + e] = ain[d * GTS + s];
+    }
+  }
+}
+
 // grad[p] += sum over slabs; the first 16 entries are per-bin adjoint sums of
 // the `first` spline and go through the softmax / softplus Jacobians (float64).
 // Block = 32 parameters x 32 slab stripes (a thread that walks all slabs alone
@@ -523,5 +582,29 @@ extern "C" int cnf_adam_step(float* params, const float* grad, float* mu, float*
   const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grad,
                      mu, nu, n, lr, b1, b2, eps, bc1, bc2);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+extern "C" int cnf_input_vjp(CnfModel* m, int to_base, const float* pts, const float* c, int64_t c_block,
+                             const float* ybar, const float* ldbar, float* xbar, int64_t B, void* stream_) {
+  if (!m || !pts || !c || !xbar || B < 0 || c_block < 1 || (!ybar && !ldbar)) return CNF_ERR_INVALID;
+  if (!m->params_set) return CNF_ERR_INVALID;
+  if (!cnf_grad_supported(&m->cfg)) return CNF_ERR_UNSUPPORTED;
+  if (B == 0) return CNF_OK;
+  VjpArgs a;
+  a.m = model_args(m); a.pts = pts; a.c = c; a.ybar = ybar; a.ldbar = ldbar; a.xbar = xbar;
+  a.B = B; a.c_block = c_block; a.to_base = to_base ? 1 : 0; a.div_magic = m->div_magic;
+  const int D = m->cfg.dim, L = m->cfg.num_layers;
+  const size_t lds = (size_t)(hdr_floats(GK) + D * GTS * ((L + 1) + 2)) * sizeof(float);
+  int64_t grid = (B + GTS - 1) / GTS;
+  if (grid > (int64_t)m->num_cus * 4) grid = (int64_t)m->num_cus * 4;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m->fast_math) {
+    if (!ensure_lds(vjp_kernel<true>, lds)) return CNF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(vjp_kernel<true>, dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+  } else {
+    if (!ensure_lds(vjp_kernel<false>, lds)) return CNF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(vjp_kernel<false>, dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }

@@ -253,6 +253,37 @@ class FlowEngine:
                                                  _stream_ptr(self.device)), "cnf_loss_terms_grad")
     return sums
 
+  def input_vjp(self, pts, cond, ybar=None, ldbar=None, to_base=False) -> torch.Tensor:
+    """cnf_input_vjp: xbar = ybar . dF/dx + ldbar * d logdet/dx of one flow pass."""
+    pts = self._points(pts, "input_vjp")
+    B = pts.shape[0]
+    c, c_block = self.cond(cond, B)
+    if ybar is not None:
+      ybar = self._check_out(self._points(ybar, "ybar"), pts.shape, "ybar")
+    if ldbar is not None:
+      ldbar = ldbar.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+      if ldbar.numel() != B:
+        raise ValueError("ldbar must have one value per sample")
+    xbar = torch.empty_like(pts)
+    if B > 0:
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_input_vjp(self._h, 1 if to_base else 0, pts.data_ptr(), c.data_ptr(), c_block,
+                                           ybar.data_ptr() if ybar is not None else None,
+                                           ldbar.data_ptr() if ldbar is not None else None,
+                                           xbar.data_ptr(), B, _stream_ptr(self.device)), "cnf_input_vjp")
+    return xbar
+
+  def jacobian(self, pts, cond, to_base=False) -> torch.Tensor:
+    """[B, D, D] Jacobian d out_i / d in_j of a flow pass: D vector-Jacobian products."""
+    pts = self._points(pts, "jacobian")
+    B, D = pts.shape
+    J = torch.empty(B, D, D, dtype=torch.float32, device=self.device)
+    for i in range(D):
+      e = torch.zeros(B, D, dtype=torch.float32, device=self.device)
+      e[:, i] = 1.0
+      J[:, i, :] = self.input_vjp(pts, cond, ybar=e, to_base=to_base)
+    return J
+
   def normal(self, seed, n_samples: int, first_sample: int = 0) -> torch.Tensor:
     """Base noise [n_samples, D]: Philox stream element (first_sample+i)*D+d."""
     seed, off = seed_to_u64(seed)
@@ -325,20 +356,23 @@ class _Apply:
   def inverse(self, params, y, c):
     return self._engine(params, y).inverse_logdet(y, c, want_logdet=False)[0]
 
-  def _no_autodiff(self, name):
-    raise NotImplementedError(
-      f"{name} is a jax.jacfwd helper with no live call site in the reference "
-      "(flows.py:203-211; only a commented use in tests/test_fit_prob.py:140-142); "
-      "it is outside the hot-path scope of this build")
-
+  # flows.py:203-211: the jax.jacfwd helpers, as vector-Jacobian products of the backward kernels
   def forward_jac(self, params, x, c):
-    self._no_autodiff("forward_jac")
+    """vmap(jacfwd(flow.bijector.forward))(x, c): [B, D, D], rows = outputs."""
+    return self._engine(params, x).jacobian(x, c, to_base=False)
 
   def inverse_jac(self, params, y, c):
-    self._no_autodiff("inverse_jac")
+    """vmap(jacfwd(flow.bijector.inverse))(y, c): [B, D, D]."""
+    return self._engine(params, y).jacobian(y, c, to_base=True)
 
   def gauge_potential(self, params, x, c):
-    self._no_autodiff("gauge_potential")
+    """jacfwd(x -> log|det J(forward)(x, c)|): the gradient of the log-det,
+    [D] for one point like the reference, [B, D] for a batch."""
+    single = torch.is_tensor(x) and x.dim() == 1
+    xx = x.reshape(1, -1) if single else x
+    eng = self._engine(params, xx)
+    g = eng.input_vjp(xx, c, ldbar=torch.ones(xx.shape[0], device=eng.device), to_base=False)
+    return g[0] if single else g
 
 
 class FlowModel:

@@ -223,6 +223,19 @@ int cnf_loss_terms_grad(CnfModel *m, const CnfLossSpec *spec, const float *pts,
                         int64_t B, float scale, double *sums, float *grad,
                         const float *params, void *stream);
 
+/* Replaces the autodiff helpers of the Flow tuple (flows.py:203-211):
+ *   forward_jac = vmap(jacfwd(flow.bijector.forward)),
+ *   inverse_jac = vmap(jacfwd(flow.bijector.inverse)),
+ *   gauge_potential = jacfwd(log|det J| of forward)
+ * through one primitive, the vector-Jacobian product of a flow pass w.r.t. its
+ * input points:  xbar[b,:] = ybar[b,:] . dF/dx(b) + ldbar[b] * d logdet/dx(b).
+ * to_base = 0: F = flow.bijector.forward (base -> data); 1: the inverse.
+ * ybar [B,D] and ldbar [B] may each be NULL (= 0), not both.  Row i of the
+ * Jacobian is the call with ybar = e_i.  Same config support as the gradients. */
+int cnf_input_vjp(CnfModel *m, int to_base, const float *pts, const float *c,
+                  int64_t c_block, const float *ybar, const float *ldbar,
+                  float *xbar, int64_t B, void *stream);
+
 /* optax.adam(lr) update in place (solvers.py:55,95-96): b1 = 0.9, b2 = 0.999,
  * eps = 1e-8 are optax's defaults; `step` counts from 1. */
 int cnf_adam_step(float *params, const float *grad, float *mu, float *nu,

@@ -95,8 +95,6 @@ def test_rqsflow_signature_and_argument_errors():
     cnf_ot_amd.RQSFlow((2,), 2, [16, 16], 5, periodized=True)
   with pytest.raises(NotImplementedError):
     cnf_ot_amd.RQSFlow((2,), 2, [16, 32], 5)
-  with pytest.raises(NotImplementedError):
-    m.apply.forward_jac(None, None, None)
 
 
 def test_no_cpu_fallback_in_product_path():

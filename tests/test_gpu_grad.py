@@ -189,3 +189,38 @@ def test_adam_step_and_training_decreases_loss(dev):
   first, last = float(torch.stack(hist[:5]).mean()), float(torch.stack(hist[-5:]).mean())
   print(f"[train ot] loss {first:.5g} -> {last:.5g} after 60 Adam steps")
   assert np.isfinite(last) and last < first
+
+
+def test_jacobian_helpers_match_finite_differences(dev):
+  """forward_jac / inverse_jac / gauge_potential (flows.py:203-211) against
+  central differences of the float64 oracle."""
+  import oracle
+  from cnf_ot_amd import RQSFlow, Params
+  for D, scale in ((2, 0.2), (3, 0.15)):
+    model = RQSFlow(event_shape=(D,), num_layers=2, hidden_sizes=[16, 16], num_bins=5)
+    params = Params.random(model.cfg, scale, seed=40 + D, device=dev)
+    ocfg = oracle.OracleConfig(D=D)
+    p64 = params.flat.cpu().double().numpy()
+    rng = np.random.default_rng(D)
+    x = rng.normal(size=(300, D)).astype(np.float32)
+    c = np.float32(0.35)
+    xt, ct = torch.from_numpy(x).to(dev), torch.tensor([c], device=dev)
+    h = 1e-6
+    Jf = np.zeros((300, D, D)); Ji = np.zeros((300, D, D)); G = np.zeros((300, D))
+    y0, _ = oracle.forward_logdet(ocfg, p64, x.astype(np.float64), [c])
+    y32 = y0.astype(np.float32)
+    for j in range(D):
+      e = np.zeros(D); e[j] = h
+      yp, lp = oracle.forward_logdet(ocfg, p64, x + e, [c]); ym, lm = oracle.forward_logdet(ocfg, p64, x - e, [c])
+      Jf[:, :, j] = (yp - ym) / (2 * h); G[:, j] = (lp - lm) / (2 * h)
+      xp, _ = oracle.inverse_logdet(ocfg, p64, y32 + e, [c]); xm, _ = oracle.inverse_logdet(ocfg, p64, y32 - e, [c])
+      Ji[:, :, j] = (xp - xm) / (2 * h)
+    jf = model.apply.forward_jac(params, xt, ct).cpu().double().numpy()
+    ji = model.apply.inverse_jac(params, torch.from_numpy(y32).to(dev), ct).cpu().double().numpy()
+    g = model.apply.gauge_potential(params, xt, ct).cpu().double().numpy()
+    g1 = model.apply.gauge_potential(params, xt[0], ct).cpu().double().numpy()
+    ef, ei, eg = np.abs(jf - Jf).max(), np.abs(ji - Ji).max(), np.abs(g - G).max()
+    print(f"[jac D={D}] forward_jac {ef:.2e} inverse_jac {ei:.2e} gauge_potential {eg:.2e}")
+    assert ef <= 2e-5 and ei <= 5e-5 and eg <= 5e-5 and np.abs(g1 - G[0]).max() <= 5e-5
+    # the two Jacobians are inverses of each other
+    assert np.abs(np.einsum("bij,bjk->bik", jf, ji) - np.eye(D)).max() <= 2e-4
