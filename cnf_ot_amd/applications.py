@@ -133,8 +133,62 @@ def _kinetic_sum(ctx, dt, conds, batch_size, coef):
   return ctx.terms(_spec(_capi.TERM_KINETIC, dt=dt), z, conds, count, coef)
 
 
+# From this dimension on, the score terms run UNFUSED: the fused kernel runs a
+# sample's 3 + 2*dim flow passes back to back on one lane, which starves the GPU
+# when a rank has few samples (dim 10: 32 768 samples = 512 waves, 23 passes
+# each).  Unfused, the 2*dim log_prob evaluations at r3 +- dx/2 e_d are just
+# 2*dim*B more points for the fast flow kernel, and the gradient comes from
+# torch.autograd over the differentiable flow passes (cnf_ot_amd.autograd).
+UNFUSED_SCORE_MIN_DIM = 6
+
+
+def _score_terms_unfused(ctx, conds, batch_size, dt, dx, coef_score, loss_coef, drift=None):
+  """per-slice sums of  sum_d ((r2-r1)/dt + coef_score * score_d(r3) - drift_d(r3))^2  as torch ops
+  over flow passes; with ctx.grad, back-propagated through cnf_pass_vjp."""
+  from . import autograd as ag
+  be = ctx.be
+  z, _, count = ctx.noise(batch_size)
+  S, D = len(conds), z.shape[1]
+  t = torch.as_tensor(np.asarray(conds, dtype=np.float32), device=z.device)
+  flat = be._flat.detach().requires_grad_(ctx.grad is not None)
+  zs = z.repeat(S, 1)                                         # the same draw for every slice
+  tt = t.repeat_interleave(count)                             # per-sample condition
+  with torch.set_grad_enabled(ctx.grad is not None):
+    r1, _ = ag.flow_forward(be, flat, zs, tt - 0.5 * dt)
+    r2, _ = ag.flow_forward(be, flat, zs, tt + 0.5 * dt)
+    r3, _ = ag.flow_forward(be, flat, zs, tt)
+    eye = torch.eye(D, device=z.device) * (0.5 * dx)
+    pts = torch.cat([(r3[:, None, :] + eye[None]).reshape(-1, D), (r3[:, None, :] - eye[None]).reshape(-1, D)])
+    lp = ag.log_prob(be, flat, pts, tt.repeat_interleave(D).repeat(2))
+    n = S * count * D
+    score = ((lp[:n] - lp[n:]) / dx).reshape(S * count, D)
+    u = (r2 - r1) / dt + coef_score * score
+    if drift is not None:
+      u = u - drift(r3)
+    sums = (u.double() ** 2).reshape(S, count * D).sum(1)
+    if ctx.grad is not None:
+      (loss_coef * sums.sum()).backward()
+      ctx.grad += flat.grad
+  return sums.detach()
+
+
+def _drift_torch(subtype, a):
+  if subtype == "ou":
+    return lambda r: -a * r
+  if subtype == "lorenz":
+    return lambda r: torch.stack([10 * (r[:, 1] - r[:, 0]), 9 * r[:, 0] * (28 / 9 - r[:, 2]) - r[:, 1],
+                                  9 * r[:, 0] * r[:, 1] - r[:, 2] * 8 / 3], dim=1)
+  raise ValueError(subtype)
+
+
+def _use_unfused(ctx, dim):
+  return dim >= UNFUSED_SCORE_MIN_DIM and hasattr(ctx.be, "pass_vjp")
+
+
 def _kinetic_score_sum(ctx, beta, dt, dx, conds, batch_size, coef):
   z, _, count = ctx.noise(batch_size)
+  if _use_unfused(ctx, z.shape[1]):
+    return _score_terms_unfused(ctx, np.atleast_1d(conds), batch_size, dt, dx, 1.0 / beta, coef)
   return ctx.terms(_spec(_capi.TERM_KINETIC_SCORE, dt=dt, dx=dx, coef=1.0 / beta), z, conds, count, coef)
 
 
@@ -149,6 +203,8 @@ def _flow_matching_sum(ctx, dim, a, sigma, subtype, conds, batch_size, coef):
     raise ValueError("the reference's 'gradient' target is a 2-D field (applications.py:353-357); "
                      "use subtype='ou' for the documented drift -a*r in other dimensions")
   z, _, count = ctx.noise(batch_size)
+  if _use_unfused(ctx, dim) and subtype in ("ou", "lorenz"):
+    return _score_terms_unfused(ctx, np.atleast_1d(conds), batch_size, 0.01, 0.01, sigma, coef, _drift_torch(subtype, a))
   # dt and dx are overridden to 0.01 inside the reference function (:286,301)
   return ctx.terms(_spec(_capi.TERM_FLOW_MATCHING, subtype=_capi.DRIFTS[subtype], dt=0.01, dx=0.01,
                          coef=sigma, a=a), z, conds, count, coef)

@@ -401,14 +401,18 @@ struct VjpArgs {
   const float* c;
   const float* ybar;     // [B, D] or null (= 0)
   const float* ldbar;    // [B] or null (= 0)
-  float* xbar;           // [B, D]
+  float* xbar;           // [B, D] or null
+  float* slabs;          // WGRAD: per-wave gradient slabs
+  int64_t n_params;
   int64_t B, c_block;
   int32_t to_base;
   uint32_t div_magic;
 };
 
-template <bool FAST>
-__global__ __launch_bounds__(TILE, 2) void vjp_kernel(const VjpArgs a) {
+// WGRAD=true additionally accumulates the parameter gradient of the pass (the
+// backward of a differentiable flow op: cnf_pass_vjp).
+template <bool FAST, bool WGRAD>
+__global__ __launch_bounds__(TILE, WGRAD ? 1 : 2) void vjp_kernel(const VjpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HDR = hdr_floats(GK);
   const int D = a.m.D, L = a.m.L, DT = D * GTS;
@@ -416,9 +420,11 @@ __global__ __launch_bounds__(TILE, 2) void vjp_kernel(const VjpArgs a) {
   float* St = lds + HDR;
   float* Aa = St + (L + 1) * DT;
   float* Ab = Aa + DT;
+  float* stage = WGRAD ? Ab + DT + (threadIdx.x >> 6) * (2 * 16 * STG) : nullptr;
+  float* gslab = WGRAD ? a.slabs + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * a.n_params : nullptr;
   for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = a.m.prep[i];
   const int tid = threadIdx.x;
-  FirstAcc fa;      // written, never read: removed by the compiler
+  FirstAcc fa;      // WGRAD=false: written, never read: removed by the compiler
 #pragma unroll
   for (int j = 0; j < GK; ++j) { fa.Wb[j] = 0.0f; fa.Hb[j] = 0.0f; }
 #pragma unroll
@@ -435,14 +441,31 @@ __global__ __launch_bounds__(TILE, 2) void vjp_kernel(const VjpArgs a) {
     const float ld_bar = (a.ldbar && i < a.B) ? a.ldbar[i] : 0.0f;
     __syncthreads();
     pass_fwd_stash<FAST>(a.m, tab, St, c, a.to_base != 0);
-    float* ain = pass_bwd<FAST, false>(a.m, tab, St, Aa, Ab, ld_bar, c, a.to_base != 0, nullptr, nullptr, fa);
+    float* ain = pass_bwd<FAST, WGRAD>(a.m, tab, St, Aa, Ab, ld_bar, c, a.to_base != 0, gslab, stage, fa);
     __syncthreads();
-    // coalesced store of the input adjoints
-    const int64_t base = tile_start * D;
-    const int n_el = (int)(a.B - tile_start < GTS ? a.B - tile_start : GTS) * D;
-    for (int e = tid; e < GTS * D; e += TILE) {
-      const int s = a.div_magic ? (int)__umulhi((uint32_t)e, a.div_magic) : e, d = e - s * D;
-      if (e < n_el) a.xbar[base + e] = ain[d * GTS + s];
+    if (a.xbar) {      // coalesced store of the input adjoints
+      const int64_t base = tile_start * D;
+      const int n_el = (int)(a.B - tile_start < GTS ? a.B - tile_start : GTS) * D;
+      for (int e = tid; e < GTS * D; e += TILE) {
+        const int s = a.div_magic ? (int)__umulhi((uint32_t)e, a.div_magic) : e, d = e - s * D;
+        if (e < n_el) a.xbar[base + e] = ain[d * GTS + s];
+      }
+    }
+  }
+  if constexpr (WGRAD) {
+    float red[GP];
+#pragma unroll
+    for (int j = 0; j < GK; ++j) { red[j] = fa.Wb[j]; red[GK + j] = fa.Hb[j]; }
+#pragma unroll
+    for (int j = 0; j <= GK; ++j) red[2 * GK + j] = fa.Db[j];
+#pragma unroll
+    for (int j = 0; j < GP; ++j) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) red[j] += __shfl_xor(red[j], off, 64);
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int j = 0; j < GP; ++j) gslab[j] += red[j];
     }
   }
 }
@@ -515,8 +538,16 @@ __global__ void adam_kernel(float* __restrict__ params, const float* __restrict_
 
 using namespace cnf;
 
+static size_t grad_lds_bytes(int D, int L) {
+  // tab + noise + (L+1) stashes + 2 adjoint buffers + velocity, r3, r3_bar, u_bar + 4 MFMA staging areas
+  return (size_t)(hdr_floats(GK) + D * GTS * (1 + (L + 1) + 6) + 4 * 2 * 16 * STG) * sizeof(float);
+}
+
 extern "C" int cnf_grad_supported(const CnfConfig* c) {
-  return c && c->hidden_size == 16 && c->mlp_num_layers == 2 && c->num_bins == 5 && c->dim >= 1 && c->dim <= 15;
+  // hidden 16 / 2 hidden layers / 5 bins (the MFMA weight-gradient tiles are 16x16), dim <= 14 (the
+  // first layer's inputs + bias row fit 16 MFMA rows), and the tile's LDS working set within one CU
+  return c && c->hidden_size == 16 && c->mlp_num_layers == 2 && c->num_bins == 5 && c->dim >= 1 && c->dim <= 14 &&
+         c->num_layers >= 1 && grad_lds_bytes(c->dim, c->num_layers) <= 160 * 1024;
 }
 
 extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const float* pts, int pts_shared,
@@ -546,7 +577,7 @@ extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const f
   a.scale = scale; a.div_magic = m->div_magic;
   int64_t grid = ((B + GTS - 1) / GTS) * n_slices;
   if (grid > m->grad_max_blocks) grid = m->grad_max_blocks;
-  const size_t lds = (size_t)(hdr_floats(GK) + D * GTS * (1 + (L + 1) + 6) + 4 * 2 * 16 * STG) * sizeof(float);
+  const size_t lds = grad_lds_bytes(D, L);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
   const int64_t n_slabs = grid * 4;
   if (hipMemsetAsync(m->grad_slabs, 0, sizeof(float) * (size_t)(n_slabs * m->n_params), stream) != hipSuccess) return CNF_ERR_HIP;
@@ -585,26 +616,60 @@ extern "C" int cnf_adam_step(float* params, const float* grad, float* mu, float*
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 
-extern "C" int cnf_input_vjp(CnfModel* m, int to_base, const float* pts, const float* c, int64_t c_block,
-                             const float* ybar, const float* ldbar, float* xbar, int64_t B, void* stream_) {
-  if (!m || !pts || !c || !xbar || B < 0 || c_block < 1 || (!ybar && !ldbar)) return CNF_ERR_INVALID;
+static int pass_vjp_impl(CnfModel* m, int to_base, const float* pts, const float* c, int64_t c_block,
+                         const float* ybar, const float* ldbar, float* xbar, float* grad, const float* params,
+                         int64_t B, void* stream_) {
+  if (!m || !pts || !c || B < 0 || c_block < 1 || (!ybar && !ldbar) || (!xbar && !grad)) return CNF_ERR_INVALID;
+  if (grad && !params) return CNF_ERR_INVALID;
   if (!m->params_set) return CNF_ERR_INVALID;
   if (!cnf_grad_supported(&m->cfg)) return CNF_ERR_UNSUPPORTED;
   if (B == 0) return CNF_OK;
+  if (grad && !m->grad_slabs) return CNF_ERR_INVALID;      // cnf_grad_enable first
+  hipStream_t stream = (hipStream_t)stream_;
   VjpArgs a;
   a.m = model_args(m); a.pts = pts; a.c = c; a.ybar = ybar; a.ldbar = ldbar; a.xbar = xbar;
+  a.slabs = m->grad_slabs; a.n_params = m->n_params;
   a.B = B; a.c_block = c_block; a.to_base = to_base ? 1 : 0; a.div_magic = m->div_magic;
   const int D = m->cfg.dim, L = m->cfg.num_layers;
-  const size_t lds = (size_t)(hdr_floats(GK) + D * GTS * ((L + 1) + 2)) * sizeof(float);
+  size_t lds = (size_t)(hdr_floats(GK) + D * GTS * ((L + 1) + 2)) * sizeof(float);
   int64_t grid = (B + GTS - 1) / GTS;
-  if (grid > (int64_t)m->num_cus * 4) grid = (int64_t)m->num_cus * 4;
-  hipStream_t stream = (hipStream_t)stream_;
-  if (m->fast_math) {
-    if (!ensure_lds(vjp_kernel<true>, lds)) return CNF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(vjp_kernel<true>, dim3((unsigned)grid), dim3(TILE), lds, stream, a);
-  } else {
-    if (!ensure_lds(vjp_kernel<false>, lds)) return CNF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(vjp_kernel<false>, dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+  if (!grad) {
+    if (grid > (int64_t)m->num_cus * 4) grid = (int64_t)m->num_cus * 4;
+    if (m->fast_math) {
+      if (!ensure_lds(vjp_kernel<true, false>, lds)) return CNF_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL((vjp_kernel<true, false>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+    } else {
+      if (!ensure_lds(vjp_kernel<false, false>, lds)) return CNF_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL((vjp_kernel<false, false>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+    }
+    return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
   }
+  lds += (size_t)(4 * 2 * 16 * STG) * sizeof(float);
+  if (grid > m->grad_max_blocks) grid = m->grad_max_blocks;
+  const int64_t n_slabs = grid * 4;
+  if (hipMemsetAsync(m->grad_slabs, 0, sizeof(float) * (size_t)(n_slabs * m->n_params), stream) != hipSuccess) return CNF_ERR_HIP;
+  if (m->fast_math) {
+    if (!ensure_lds(vjp_kernel<true, true>, lds)) return CNF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((vjp_kernel<true, true>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+  } else {
+    if (!ensure_lds(vjp_kernel<false, true>, lds)) return CNF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((vjp_kernel<false, true>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+  }
+  if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
+  const int fb = (int)((m->n_params + 31) / 32);
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, n_slabs, m->n_params, params,
+                     grad, (double)m->sc.span_eff, (double)m->sc.sp_offset);
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+extern "C" int cnf_input_vjp(CnfModel* m, int to_base, const float* pts, const float* c, int64_t c_block,
+                             const float* ybar, const float* ldbar, float* xbar, int64_t B, void* stream) {
+  if (!xbar) return CNF_ERR_INVALID;
+  return pass_vjp_impl(m, to_base, pts, c, c_block, ybar, ldbar, xbar, nullptr, nullptr, B, stream);
+}
+
+extern "C" int cnf_pass_vjp(CnfModel* m, int to_base, const float* pts, const float* c, int64_t c_block,
+                            const float* ybar, const float* ldbar, float* xbar, float* grad, const float* params,
+                            int64_t B, void* stream) {
+  return pass_vjp_impl(m, to_base, pts, c, c_block, ybar, ldbar, xbar, grad, params, B, stream);
 }

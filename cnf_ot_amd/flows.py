@@ -273,6 +273,34 @@ class FlowEngine:
                                            xbar.data_ptr(), B, _stream_ptr(self.device)), "cnf_input_vjp")
     return xbar
 
+  def pass_vjp(self, pts, cond, ybar, ldbar, to_base, grad=None, want_xbar=True):
+    """cnf_pass_vjp: input adjoints (returned, or None) and, into `grad`, the
+    parameter gradient of one flow pass for the output adjoints (ybar, ldbar)."""
+    pts = self._points(pts, "pass_vjp")
+    B = pts.shape[0]
+    c, c_block = self.cond(cond, B)
+    ybar = None if ybar is None else self._check_out(self._points(ybar, "ybar"), pts.shape, "ybar")
+    ldbar = None if ldbar is None else ldbar.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+    if grad is not None:
+      if self._flat is None:
+        raise RuntimeError("load(params) before asking for gradients")
+      if not getattr(self, "_grad_enabled", False):
+        with torch.cuda.device(self.device):
+          _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
+        self._grad_enabled = True
+      self._check_out(grad, (self.cfg.param_count(),), "grad")
+    xbar = torch.empty_like(pts) if want_xbar else None
+    if B > 0:
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_pass_vjp(self._h, 1 if to_base else 0, pts.data_ptr(), c.data_ptr(), c_block,
+                                          ybar.data_ptr() if ybar is not None else None,
+                                          ldbar.data_ptr() if ldbar is not None else None,
+                                          xbar.data_ptr() if xbar is not None else None,
+                                          grad.data_ptr() if grad is not None else None,
+                                          self._flat.data_ptr() if grad is not None else None, B,
+                                          _stream_ptr(self.device)), "cnf_pass_vjp")
+    return xbar
+
   def jacobian(self, pts, cond, to_base=False) -> torch.Tensor:
     """[B, D, D] Jacobian d out_i / d in_j of a flow pass: D vector-Jacobian products."""
     pts = self._points(pts, "jacobian")

@@ -205,7 +205,10 @@ int cnf_loss_terms_seeded(CnfModel *m, const CnfLossSpec *spec, uint64_t seed,
 
 /* ---- value_and_grad + Adam (cnf_ot/mfc/solvers.py:90-97) -------------------
  * Backward pass of the loss terms, for the reference's network (hidden 16, two
- * hidden layers, 5 bins, dim <= 15): cnf_grad_supported() tells.
+ * hidden layers, 5 bins; dim <= 12 at two flow layers -- the tile's working set
+ * must fit one CU's LDS): cnf_grad_supported() tells.  A model's gradient
+ * slabs are shared state: do not run two gradient calls of the same model
+ * concurrently on different streams.
  *
  * cnf_grad_enable allocates the per-wave gradient slabs (the only allocation;
  * call once, outside any graph capture; max_blocks <= 0: a default).
@@ -235,6 +238,18 @@ int cnf_loss_terms_grad(CnfModel *m, const CnfLossSpec *spec, const float *pts,
 int cnf_input_vjp(CnfModel *m, int to_base, const float *pts, const float *c,
                   int64_t c_block, const float *ybar, const float *ldbar,
                   float *xbar, int64_t B, void *stream);
+
+/* The backward of a differentiable flow op: cnf_input_vjp PLUS the parameter
+ * gradient of the same pass,
+ *   grad[p] += sum_b ( ybar[b,:] . dF/dp(b) + ldbar[b] * d logdet/dp(b) ),
+ * so that any loss composed on the host from flow passes (e.g. under
+ * torch.autograd: cnf_ot_amd/autograd.py) gets exact gradients -- what
+ * jax.value_and_grad gives the reference for losses not in applications.py.
+ * xbar may be NULL; grad is accumulated (needs cnf_grad_enable). */
+int cnf_pass_vjp(CnfModel *m, int to_base, const float *pts, const float *c,
+                 int64_t c_block, const float *ybar, const float *ldbar,
+                 float *xbar, float *grad, const float *params, int64_t B,
+                 void *stream);
 
 /* optax.adam(lr) update in place (solvers.py:55,95-96): b1 = 0.9, b2 = 0.999,
  * eps = 1e-8 are optax's defaults; `step` counts from 1. */

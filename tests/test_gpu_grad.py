@@ -224,3 +224,46 @@ def test_jacobian_helpers_match_finite_differences(dev):
     assert ef <= 2e-5 and ei <= 5e-5 and eg <= 5e-5 and np.abs(g1 - G[0]).max() <= 5e-5
     # the two Jacobians are inverses of each other
     assert np.abs(np.einsum("bij,bjk->bik", jf, ji) - np.eye(D)).max() <= 2e-4
+
+
+def test_autograd_flow_passes_and_unfused_score_terms(dev):
+  """cnf_pass_vjp under torch.autograd: (1) gradient of a host-composed loss ==
+  the fused kernel's gradient of the same loss; (2) the unfused dim-10 score
+  path == the fused kernel (value and gradient)."""
+  from cnf_ot_amd import FlowConfig, FlowModel, Params, _capi
+  from cnf_ot_amd import applications as app, autograd as ag
+  # (1) dim 2: -mean log_prob of data points, and a sampled potential
+  cfg = FlowConfig(dim=2); model = FlowModel(cfg)
+  params = Params.random(cfg, 0.2, seed=50, device=dev)
+  eng = model.terms_backend(params)
+  pts = eng.normal(3, 1000) * 1.3 + 0.2
+  flat = params.flat.clone().requires_grad_(True)
+  loss = -ag.log_prob(eng, flat, pts, torch.tensor([0.4], device=dev)).double().sum()
+  loss.backward()
+  g_fused = torch.zeros_like(params.flat)
+  s = eng.loss_terms_grad(app._spec(_capi.TERM_NEG_LOGPROB), pts, [0.4], 1000, True, 1.0, g_fused)
+  assert abs(float(loss.detach()) - float(s.sum())) <= 1e-6 * abs(float(loss.detach()))
+  rel = (flat.grad - g_fused).abs().max().item() / g_fused.abs().max().item()
+  print(f"\n[autograd neg_logprob] rel diff vs fused gradient {rel:.2e}")
+  assert rel <= 1e-5
+  x = eng.normal(4, 1000).requires_grad_(True)
+  y, ld = ag.flow_forward(eng, flat, x, torch.tensor([0.7], device=dev))
+  (y.pow(2).sum() + ld.sum()).backward()          # exercises the input adjoint too
+  assert torch.isfinite(x.grad).all() and x.grad.abs().max() > 0
+  # (2) dim 10 score terms: unfused (autograd) vs fused kernel
+  cfg10 = FlowConfig(dim=10); m10 = FlowModel(cfg10)
+  p10 = Params.random(cfg10, 0.12, seed=51, device=dev)
+  B, seed = 2048, 6
+  out = {}
+  for mode, min_dim in (("unfused", 6), ("fused", 99)):
+    app.UNFUSED_SCORE_MIN_DIM = min_dim
+    g = torch.zeros_like(p10.flat)
+    loss = app.fp_loss_fn(m10, 10, 1.0, 1.0, 0.5, 0.01, 0.01, 2, "ou", p10, seed, 5000.0, B, grad=g)
+    loss_ng = app.fp_loss_fn(m10, 10, 1.0, 1.0, 0.5, 0.01, 0.01, 2, "ou", p10, seed, 5000.0, B)
+    assert abs(float(loss) - float(loss_ng)) <= 1e-6 * abs(float(loss_ng))
+    out[mode] = (float(loss), g.clone())
+  app.UNFUSED_SCORE_MIN_DIM = 6
+  dl = abs(out["fused"][0] - out["unfused"][0]) / abs(out["fused"][0])
+  dg = (out["fused"][1] - out["unfused"][1]).abs().max().item() / out["fused"][1].abs().max().item()
+  print(f"[dim10 fp loss] fused {out['fused'][0]:.8g} unfused {out['unfused'][0]:.8g} rel {dl:.2e}; gradient rel {dg:.2e}")
+  assert dl <= 1e-5 and dg <= 2e-3
