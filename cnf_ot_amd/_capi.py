@@ -79,6 +79,7 @@ _INTERNAL = {
   "cnf_model_set_fast_math": (ctypes.c_int, [_P, ctypes.c_int]),
   "cnf_model_set_samples_per_lane": (ctypes.c_int, [_P, ctypes.c_int]),
   "cnf_model_set_mfma": (ctypes.c_int, [_P, ctypes.c_int]),
+  "cnf_model_set_pwl": (ctypes.c_int, [_P, ctypes.c_int]),
 }
 
 _lib = None

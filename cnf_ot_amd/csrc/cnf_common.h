@@ -74,6 +74,9 @@ struct CnfModel {
   int params_set;
   float* grad_slabs;      // per-wave gradient slabs (cnf_grad_enable), or null
   int64_t grad_max_blocks;
+  int use_pwl;            // 1: piecewise-linear conditioner tables at dim 2 (cnf_pwl.h)
+  float* pwl_tables;      // [pwl_slices][L][PWL_TBL] workspace, grown on demand
+  int64_t pwl_slices;
 };
 
 #ifdef CNF_MINIMAL_CONFIGS   /* faster builds while iterating on the kernels */

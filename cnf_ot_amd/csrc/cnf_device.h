@@ -103,6 +103,7 @@ __device__ __forceinline__ double vmax(double a, double b) { return fmax(a, b); 
 __device__ __forceinline__ double vabs(double a) { return fabs(a); }
 __device__ __forceinline__ double vrelu(double a) { return fmax(a, 0.0); }
 __device__ __forceinline__ double clip01(double z) { return fmin(fmax(z, 0.0), 1.0); }
+__device__ __forceinline__ double vclamp(double z, double hi) { return fmin(fmax(z, 0.0), hi); }
 __device__ __forceinline__ bool vge(double a, double b) { return a >= b; }
 __device__ __forceinline__ bool vle(double a, double b) { return a <= b; }
 __device__ __forceinline__ bool vlt(double a, double b) { return a < b; }
@@ -120,8 +121,11 @@ __device__ __forceinline__ float vabs(float a) { return fabsf(a); }
 __device__ __forceinline__ v2f vabs(v2f a) { return v2f{fabsf(a.x), fabsf(a.y)}; }
 __device__ __forceinline__ float vrelu(float a) { return fmaxf(a, 0.0f); }
 __device__ __forceinline__ v2f vrelu(v2f a) { return v2f{fmaxf(a.x, 0.0f), fmaxf(a.y, 0.0f)}; }
-__device__ __forceinline__ float clip01(float z) { return fminf(fmaxf(z, 0.0f), 1.0f); }
+// clamp to [0, 1] / [0, hi] (hi > 0) in one v_med3_f32
+__device__ __forceinline__ float clip01(float z) { return __builtin_amdgcn_fmed3f(z, 0.0f, 1.0f); }
 __device__ __forceinline__ v2f clip01(v2f z) { return v2f{clip01(z.x), clip01(z.y)}; }
+__device__ __forceinline__ float vclamp(float z, float hi) { return __builtin_amdgcn_fmed3f(z, 0.0f, hi); }
+__device__ __forceinline__ v2f vclamp(v2f z, v2f hi) { return v2f{vclamp(z.x, hi.x), vclamp(z.y, hi.y)}; }
 
 __device__ __forceinline__ bool vge(float a, float b) { return a >= b; }
 __device__ __forceinline__ v2i vge(v2f a, v2f b) { return a >= b; }
@@ -135,6 +139,17 @@ __device__ __forceinline__ float vsel(bool m, float a, float b) { return m ? a :
 __device__ __forceinline__ v2f vsel(v2i m, v2f a, v2f b) { return v2f{m.x ? a.x : b.x, m.y ? a.y : b.y}; }
 __device__ __forceinline__ bool vany(bool m) { return m; }
 __device__ __forceinline__ bool vany(v2i m) { return (m.x | m.y) != 0; }
+
+// "Might this lane need the linear tails?" -- a cheap, slightly conservative
+// test (the tail code itself applies the exact v <= lo / v >= hi masks): three
+// VALU instructions for a sample pair instead of four compares and the mask
+// arithmetic.
+template <class R> __device__ __forceinline__ bool maybe_outside(R v, R lo, R hi) { return v <= lo || v >= hi; }
+__device__ __forceinline__ bool maybe_outside(v2f v, float lo, float hi) {
+  const float mid = 0.5f * (lo + hi), half = 0.5f * (hi - lo) * 0.99999f;
+  const v2f d = v - mid;
+  return !(fmaxf(fabsf(d.x), fabsf(d.y)) < half);     // NaN counts as outside
+}
 
 // ---------------------------------------------------------------------------
 // Math policy.  FAST=false: ocml expf/logf/sqrtf and IEEE division.
@@ -158,6 +173,9 @@ template <> struct Math<false> {
   static __device__ __forceinline__ double div(double a, double b) { return a / b; }
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ v2f exp(v2f x) { return v2f{expf(x.x), expf(x.y)}; }
+  static __device__ __forceinline__ float exp2(float x) { return exp2f(x); }
+  static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
+  static __device__ __forceinline__ v2f exp2(v2f x) { return v2f{exp2f(x.x), exp2f(x.y)}; }
   static __device__ __forceinline__ v2f log(v2f x) { return v2f{logf(x.x), logf(x.y)}; }
   static __device__ __forceinline__ v2f rcp(v2f x) { return v2f{1.0f / x.x, 1.0f / x.y}; }
   static __device__ __forceinline__ v2f div(v2f a, v2f b) { return v2f{a.x / b.x, a.y / b.y}; }
@@ -180,6 +198,8 @@ template <> struct Math<true> {
     const v2f t = x * LOG2E;
     return v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
   }
+  static __device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+  static __device__ __forceinline__ v2f exp2(v2f x) { return v2f{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
   static __device__ __forceinline__ v2f log(v2f x) {
     return v2f{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)} * LN2;
   }
@@ -196,9 +216,9 @@ template <> struct Math<true> {
 };
 
 // softplus(t + offset) + m  (distrax _normalize_knot_slopes)
-template <bool FAST, class T>
+template <bool FAST, class T, bool OFFSET_ADDED = false>
 __device__ __forceinline__ T knot_slope(T t, const SplineConstsT<typename Lanes<T>::real>& sc) {
-  const T v = t + sc.sp_offset;
+  const T v = OFFSET_ADDED ? t : t + sc.sp_offset;
   const T e = Math<FAST>::exp(-vabs(v));
   // log1p(e), e in (0,1].  Both forms are evaluated and selected: a branch
   // here would split the wave's straight-line code.
@@ -217,16 +237,20 @@ __device__ __forceinline__ T knot_slope(T t, const SplineConstsT<typename Lanes<
 
 // Shared tail of both directions: from the selected bin to (out, logdet).
 // INV=false: distrax _rational_quadratic_spline_fwd; INV=true: ..._inv.
-template <bool INV, bool FAST, class T>
-__device__ __forceinline__ void rqs_bin_eval(T v, T x0, T y0, T bw, T bh, T ibw, T ibh, T s, T st,
+// The inverse solves a z^2 + b z + c = 0 (distrax: a = s - b, b = d0 - st w,
+// c = -s w with w = (v - y0) / bh) scaled through by bh -- the root does not
+// change and 1 / bh is never needed.  L2S_GIVEN: 2 log s comes from the caller
+// (the prepared table); otherwise it is folded into the one logarithm.
+template <bool INV, bool FAST, class T, bool L2S_GIVEN = true>
+__device__ __forceinline__ void rqs_bin_eval(T v, T x0, T y0, T bw, T bh, T ibw, T s, T st,
                                              T d0, T d1, T l2s, T& out, T& ld) {
   using M = Math<FAST>;
   T z;
   if (INV) {
-    const T w = clip01((v - y0) * ibh);
-    const T c = -s * w;
-    const T b = vfma(-st, w, d0);
-    const T a = s - b;
+    const T dy = vclamp(v - y0, bh);              // bh * w, w clipped to [0, 1]
+    const T c = -s * dy;
+    const T b = vfma(-st, dy, d0 * bh);
+    const T a = vfma(s, bh, -b);
     const T disc = vfma(b, b, a * c * -4.0f);
     z = clip01(M::div(c * -2.0f, b + M::sqrt(disc)));
     out = vfma(bw, z, x0);
@@ -240,8 +264,14 @@ __device__ __forceinline__ void rqs_bin_eval(T v, T x0, T y0, T bw, T bh, T ibw,
   const T iden = M::rcp(den);
   if (!INV) out = vfma(bh * vfma(s, sq_z, d0 * z1mz), iden, y0);
   const T num2 = vfma(d1, sq_z, vfma(s * 2.0f, z1mz, d0 * omz * omz));
-  // 2 log s + log(num2) - 2 log(den) = l2s + log(num2 / den^2)
-  const T ldf = l2s + M::log(num2 * iden * iden);
+  // 2 log s + log(num2) - 2 log(den)
+  T ldf;
+  if (L2S_GIVEN) {
+    ldf = l2s + M::log(num2 * iden * iden);
+  } else {
+    const T q = s * iden;
+    ldf = M::log(num2 * q * q);
+  }
   ld = INV ? -ldf : ldf;
 }
 
@@ -255,8 +285,18 @@ template <int K, class R> __device__ __forceinline__ int bin_of(const R* pos, R 
   for (int j = 1; j < K; ++j) k += (v >= pos[j]) ? 1 : 0;
   return k;
 }
+// Two samples: the sign bits of (knot - v), one packed subtract per knot for
+// both samples (v exactly on a knot lands in the lower bin; the spline is
+// continuous there).
 template <int K> __device__ __forceinline__ v2i bin_of(const float* pos, v2f v) {
-  return v2i{bin_of<K>(pos, v.x), bin_of<K>(pos, v.y)};
+  uint32_t kx = 0, ky = 0;
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+    const v2f t = splat<v2f>(pos[j]) - v;
+    kx += __float_as_uint(t.x) >> 31;
+    ky += __float_as_uint(t.y) >> 31;
+  }
+  return v2i{(int)kx, (int)ky};
 }
 template <int K, class R> __device__ __forceinline__ R gather(const R* tab, int f, int k) {
   return tab[tab_off(f, K) + k];
@@ -265,19 +305,41 @@ template <int K> __device__ __forceinline__ v2f gather(const float* tab, int f, 
   return v2f{tab[tab_off(f, K) + k.x], tab[tab_off(f, K) + k.y]};
 }
 
+// The selected bin's row of the prepared table.  For sample pairs: two LDS
+// pointers (table base + bin, one v_add each); every field is then ONE
+// ds_read_b32 per sample with the field offset as the instruction's immediate,
+// landing directly in its half of the pair.  volatile keeps the reads from being
+// merged into ds_read2_b32, whose results would need a v_mov per field to re-pair.
+template <class T> struct BinRow {
+  const typename Lanes<T>::real* p;
+  __device__ __forceinline__ BinRow(const typename Lanes<T>::real* tab, int k) : p(tab + k) {}
+  template <int K> __device__ __forceinline__ T get(int f) const { return p[tab_off(f, K)]; }
+};
+template <> struct BinRow<v2f> {
+  typedef const volatile float __attribute__((address_space(3))) * lds_ptr;
+  lds_ptr px, py;
+  __device__ __forceinline__ BinRow(const float* tab, v2i k) {
+    lds_ptr t = (lds_ptr)(uintptr_t)(uint32_t)(uintptr_t)tab;       // low 32 bits of a flat LDS address = LDS offset
+    px = t + k.x;
+    py = t + k.y;
+  }
+  template <int K> __device__ __forceinline__ v2f get(int f) const { return v2f{px[tab_off(f, K)], py[tab_off(f, K)]}; }
+};
+
 template <int K, bool INV, bool FAST, class T>
 __device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab, T v,
                                              const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld) {
   typedef typename Lanes<T>::real R;
   const R* pos = tab + tab_off(INV ? F_YK : F_XK, K);
   const typename Lanes<T>::index k = bin_of<K>(pos, v);
-  rqs_bin_eval<INV, FAST, T>(v, gather<K>(tab, F_X0, k), gather<K>(tab, F_Y0, k), gather<K>(tab, F_BW, k),
-                             gather<K>(tab, F_BH, k), gather<K>(tab, F_IBW, k), gather<K>(tab, F_IBH, k),
-                             gather<K>(tab, F_S, k), gather<K>(tab, F_ST, k), gather<K>(tab, F_D0, k),
-                             gather<K>(tab, F_D1, k), gather<K>(tab, F_L2S, k), out, ld);
-  const auto below = vle(v, sc.lo);
-  const auto above = vge(v, sc.hi);
-  if (vany(below) || vany(above)) {      // linear tails (rare: |v| >= 10)
+  const BinRow<T> row(tab, k);
+  rqs_bin_eval<INV, FAST, T>(v, row.template get<K>(F_X0), row.template get<K>(F_Y0), row.template get<K>(F_BW),
+                             row.template get<K>(F_BH), row.template get<K>(F_IBW),
+                             row.template get<K>(F_S), row.template get<K>(F_ST), row.template get<K>(F_D0),
+                             row.template get<K>(F_D1), row.template get<K>(F_L2S), out, ld);
+  if (maybe_outside(v, sc.lo, sc.hi)) {   // linear tails (rare: |v| >= 10)
+    const auto below = vle(v, sc.lo);
+    const auto above = vge(v, sc.hi);
     const R* tl = tab + tab_off(F_TAIL, K);
     const T lo_out = INV ? vfma(v - sc.lo, splat<T>(tl[T_INV_DLO]), splat<T>(sc.lo))
                          : vfma(v - sc.lo, splat<T>(tl[T_DLO]), splat<T>(sc.lo));
@@ -296,7 +358,10 @@ __device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab,
 // over the running knot (registers cannot be indexed per lane); only the two
 // slopes of the selected bin are normalised (2 softplus instead of K+1).
 // ---------------------------------------------------------------------------
-template <int K, bool INV, bool FAST, class T>
+// PRE: `th` comes from the piecewise-linear tables (cnf_pwl.h), whose rows hold
+// the softmax logits in log2 units and the slope logits with the softplus
+// offset already added.
+template <int K, bool INV, bool FAST, class T, bool PRE = false>
 __device__ __forceinline__ void cond_spline(const T (&th)[3 * K + 1], T v,
                                             const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld) {
   using M = Math<FAST>;
@@ -307,8 +372,8 @@ __device__ __forceinline__ void cond_spline(const T (&th)[3 * K + 1], T v,
   T sw = splat<T>(0.0f), sh = splat<T>(0.0f);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    ew[k] = M::exp(th[k] - mw);
-    eh[k] = M::exp(th[K + k] - mh);
+    ew[k] = PRE ? M::exp2(th[k] - mw) : M::exp(th[k] - mw);
+    eh[k] = PRE ? M::exp2(th[K + k] - mh) : M::exp(th[K + k] - mh);
     sw += ew[k];
     sh += eh[k];
   }
@@ -327,15 +392,14 @@ __device__ __forceinline__ void cond_spline(const T (&th)[3 * K + 1], T v,
     bw = vsel(ge, wk, bw); bh = vsel(ge, hk, bh);
     t0 = vsel(ge, th[2 * K + k], t0); t1 = vsel(ge, th[2 * K + k + 1], t1);
   }
-  const T d0 = knot_slope<FAST, T>(t0, sc), d1 = knot_slope<FAST, T>(t1, sc);
-  const T ibw = M::rcp(bw), ibh = M::rcp(bh);
+  const T d0 = knot_slope<FAST, T, PRE>(t0, sc), d1 = knot_slope<FAST, T, PRE>(t1, sc);
+  const T ibw = M::rcp(bw);
   const T s = bh * ibw;
   const T st = d1 + d0 - s * 2.0f;
-  const T l2s = M::log(s) * 2.0f;
-  rqs_bin_eval<INV, FAST, T>(v, x0, y0, bw, bh, ibw, ibh, s, st, d0, d1, l2s, out, ld);
-  const auto below = vle(v, sc.lo);          // bin 0 was selected: d0 = slope[0]
-  const auto above = vge(v, sc.hi);          // bin K-1 was selected: d1 = slope[K]
-  if (vany(below) || vany(above)) {
+  rqs_bin_eval<INV, FAST, T, false>(v, x0, y0, bw, bh, ibw, s, st, d0, d1, s, out, ld);
+  if (maybe_outside(v, sc.lo, sc.hi)) {
+    const auto below = vle(v, sc.lo);          // bin 0 was selected: d0 = slope[0]
+    const auto above = vge(v, sc.hi);          // bin K-1 was selected: d1 = slope[K]
     const T lo_out = INV ? M::div(v - sc.lo, d0) + sc.lo : vfma(v - sc.lo, d0, splat<T>(sc.lo));
     const T hi_out = INV ? M::div(v - sc.hi, d1) + sc.hi : vfma(v - sc.hi, d1, splat<T>(sc.hi));
     const T ld0 = M::log(d0), ld1 = M::log(d1);

@@ -15,6 +15,7 @@
 //    set) into a 12-float-per-bin table that is staged in LDS and gathered by
 //    per-lane bin index.
 #include "cnf_common.h"
+#include "cnf_pwl.h"
 
 #include <math.h>
 #include <new>
@@ -305,6 +306,96 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
     if (a.out) {
       __syncthreads();
       tile_store<R>(a.out, U, a.m.D, a.div_magic, TS, tile_start, a.B);
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// flow_pwl_kernel: the dim-2 flow with the conditioner read from the exact
+// piecewise-linear tables of cnf_pwl.h (condition uniform per slice).  One
+// 1024-thread workgroup per CU keeps the L tables of its current slice in LDS
+// (L x 40 KB); each lane owns two consecutive samples, whose 4 input floats
+// are one 16-byte load and whose outputs are one 16-byte + one 8-byte store
+// -- no LDS staging of the points at all.
+// ---------------------------------------------------------------------------
+constexpr int PWL_THREADS = 1024;
+constexpr int PWL_TS = 2 * PWL_THREADS;
+
+struct PwlArgs {
+  ModelArgs m;
+  const float* in;
+  float* out;
+  float* aux;
+  const float* tables;
+  int64_t B, slice_len;
+  int32_t n_slices, tiles_per_slice, aux_mode;
+};
+
+template <int K, bool TO_BASE, bool FAST>
+__global__ __launch_bounds__(PWL_THREADS) void flow_pwl_kernel(const PwlArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  constexpr int HDR = (hdr_floats(K) + 3) & ~3;
+  constexpr bool INV = !TO_BASE;
+  float* tab = lds_raw;
+  float* tbl = lds_raw + HDR;
+  const int tid = threadIdx.x;
+  const int L = a.m.L;
+  for (int i = tid; i < hdr_floats(K); i += PWL_THREADS) tab[i] = table_of<float>(a.m)[i];
+  const SplineConsts& sc = sc_of<float>(a.m);
+
+  const int total = a.n_slices * a.tiles_per_slice;
+  const int per_block = (total + gridDim.x - 1) / gridDim.x;
+  const int t0 = blockIdx.x * per_block;
+  const int t1 = t0 + per_block < total ? t0 + per_block : total;
+  int cur = -1;
+  for (int tile = t0; tile < t1; ++tile) {
+    const int slice = tile / a.tiles_per_slice;
+    if (slice != cur) {
+      __syncthreads();
+      const f4* src = reinterpret_cast<const f4*>(a.tables + (int64_t)slice * L * PWL_TBL);
+      f4* dst = reinterpret_cast<f4*>(tbl);
+      for (int i = tid; i < L * PWL_TBL / 4; i += PWL_THREADS) dst[i] = src[i];
+      cur = slice;
+      __syncthreads();
+    }
+    const int64_t s0 = (int64_t)slice * a.slice_len;
+    const int64_t len = a.B - s0 < a.slice_len ? a.B - s0 : a.slice_len;
+    const int64_t j = (int64_t)(tile - slice * a.tiles_per_slice) * PWL_TS + 2 * tid;
+    const int64_t g = s0 + j;
+    const bool v0 = j < len, v1 = j + 1 < len;
+    f4 x = {0.f, 0.f, 0.f, 0.f};
+    if (v1) x = *reinterpret_cast<const f4*>(a.in + 2 * g);
+    else if (v0) { x[0] = a.in[2 * g]; x[1] = a.in[2 * g + 1]; }
+    v2f u0 = {x[0], x[2]}, u1 = {x[1], x[3]};
+
+    v2f base = splat<v2f>(0.0f);
+    if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = (u0 * u0 + u1 * u1) * -0.5f - (float)(2 * HALF_LOG_2PI);
+    v2f acc = splat<v2f>(0.0f);
+    for (int step = 0; step < L; ++step) {
+      const int l = TO_BASE ? L - 1 - step : step;
+      const bool odd = l & 1;                     // flows.py:141-143 perms
+      const v2f uf = odd ? u1 : u0, uo = odd ? u0 : u1;
+      v2f of, oo, ld;
+      table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld);
+      acc += ld;
+      v2f th[PWL_P];
+      pwl_eval(tbl + l * PWL_TBL, TO_BASE ? of : uf, th);
+      cond_spline<K, INV, FAST, v2f, true>(th, uo, sc, oo, ld);
+      acc += ld;
+      u0 = odd ? oo : of;
+      u1 = odd ? of : oo;
+    }
+    if (a.aux) {
+      v2f r = acc;
+      if (a.aux_mode == AUX_LOGPROB)
+        r = TO_BASE ? (u0 * u0 + u1 * u1) * -0.5f - (float)(2 * HALF_LOG_2PI) + acc : base - acc;
+      if (v1) *reinterpret_cast<v2f*>(a.aux + g) = r;
+      else if (v0) a.aux[g] = r.x;
+    }
+    if (a.out) {
+      if (v1) *reinterpret_cast<f4*>(a.out + 2 * g) = f4{u0.x, u1.x, u0.y, u1.y};
+      else if (v0) { a.out[2 * g] = u0.x; a.out[2 * g + 1] = u1.x; }
     }
   }
 }
@@ -612,6 +703,9 @@ extern "C" int cnf_model_create(const CnfConfig* cfg, CnfModel** out) {
   // fp32 VALU do not overlap on gfx950 (their busy times add up: profiles/r01c),
   // and at equal peak rate the packed-VALU conditioner is 4-5 % faster.
   m->use_mfma = 0;
+  m->use_pwl = 1;
+  m->pwl_tables = nullptr;
+  m->pwl_slices = 0;
   // (D = 1 would need 2^32: encoded as 0, tile_load/tile_store take s = e)
   m->div_magic = cfg->dim == 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + (uint64_t)cfg->dim - 1) / (uint64_t)cfg->dim);
   m->per_layer_q = 0; m->mfma_off = 0;
@@ -637,6 +731,7 @@ extern "C" void cnf_model_destroy(CnfModel* m) {
   if (!m) return;
   if (m->prep) (void)hipFree(m->prep);
   if (m->grad_slabs) (void)hipFree(m->grad_slabs);
+  if (m->pwl_tables) (void)hipFree(m->pwl_tables);
   delete m;
 }
 
@@ -652,6 +747,14 @@ extern "C" int cnf_model_set_fast_math(CnfModel* m, int on) {
 extern "C" int cnf_model_set_mfma(CnfModel* m, int on) {
   if (!m) return CNF_ERR_INVALID;
   m->use_mfma = on ? 1 : 0;
+  return CNF_OK;
+}
+
+/* Internal knob: 1 = piecewise-linear conditioner tables at dim 2 for large launches (default),
+ * 2 = for every launch they apply to (tests), 0 = always evaluate the MLP. */
+extern "C" int cnf_model_set_pwl(CnfModel* m, int mode) {
+  if (!m || mode < 0 || mode > 2) return CNF_ERR_INVALID;
+  m->use_pwl = mode;
   return CNF_OK;
 }
 
@@ -718,12 +821,70 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
   return CNF_ERR_UNSUPPORTED;
 }
 
+// The piecewise-linear path (cnf_pwl.h): dim 2, H = 16, K = 5, two MLP layers, a condition that is
+// uniform over slices of even length, 16-byte aligned points.  Returns CNF_ERR_UNSUPPORTED when the
+// launch does not qualify (the caller then runs the MLP kernel).
+static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float* c, int64_t c_block,
+                        float* out, float* aux, int aux_mode, int64_t B, hipStream_t stream) {
+  const CnfConfig& g = m->cfg;
+  if (!m->use_pwl || !m->fast_math || g.dim != 2 || g.hidden_size != cnf::PWL_H || g.num_bins != 5 ||
+      g.mlp_num_layers != 2)
+    return CNF_ERR_UNSUPPORTED;
+  const int L = g.num_layers;
+  const size_t lds = (size_t)(((cnf::hdr_floats(5) + 3) & ~3) + L * cnf::PWL_TBL) * sizeof(float);
+  if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
+  const int64_t slice_len = c_block < B ? c_block : B;
+  const int64_t n_slices = (B + slice_len - 1) / slice_len;
+  if (n_slices > 1 && (slice_len & 1)) return CNF_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
+      (reinterpret_cast<uintptr_t>(aux) & 7))
+    return CNF_ERR_UNSUPPORTED;
+  const int64_t tps = (slice_len + cnf::PWL_TS - 1) / cnf::PWL_TS;
+  const int64_t total = n_slices * tps;
+  if (total > (1 << 30)) return CNF_ERR_UNSUPPORTED;
+  // the tables cost one small kernel per launch and 1024-thread workgroups: worth it once every CU has a tile,
+  // and only while a slice is long enough to amortise building its tables
+  if (m->use_pwl == 1 && (total < m->num_cus || slice_len < 4 * cnf::PWL_TS)) return CNF_ERR_UNSUPPORTED;
+  if (m->pwl_slices < n_slices) {
+    // grow the workspace (the only allocation in a compute entry point; reserve with a first call at the
+    // largest slice count before capturing a graph)
+    if (m->pwl_tables) {
+      if (hipStreamSynchronize(stream) != hipSuccess) return CNF_ERR_HIP;
+      (void)hipFree(m->pwl_tables);
+      m->pwl_tables = nullptr; m->pwl_slices = 0;
+    }
+    if (hipMalloc((void**)&m->pwl_tables, sizeof(float) * (size_t)n_slices * L * cnf::PWL_TBL) != hipSuccess) return CNF_ERR_HIP;
+    m->pwl_slices = n_slices;
+  }
+  hipLaunchKernelGGL(cnf::pwl_build_kernel, dim3((unsigned)(n_slices * L)), dim3(512), 0, stream,
+                     (const float*)(m->prep + cnf::hdr_floats(5)), m->per_layer, c, 0.0f, L,
+                     log(exp(1.0 - (double)m->cfg.min_knot_slope) - 1.0), m->pwl_tables);
+  cnf::PwlArgs a;
+  a.m = model_args(m);
+  a.in = in; a.out = out; a.aux = aux; a.tables = m->pwl_tables;
+  a.B = B; a.slice_len = slice_len;
+  a.n_slices = (int32_t)n_slices; a.tiles_per_slice = (int32_t)tps; a.aux_mode = aux_mode;
+  int64_t grid = total < m->num_cus ? total : m->num_cus;
+  if (to_base) {
+    if (!ensure_lds(cnf::flow_pwl_kernel<5, true, true>, lds)) return CNF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, true, true>), dim3((unsigned)grid), dim3(cnf::PWL_THREADS), lds, stream, a);
+  } else {
+    if (!ensure_lds(cnf::flow_pwl_kernel<5, false, true>, lds)) return CNF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, false, true>), dim3((unsigned)grid), dim3(cnf::PWL_THREADS), lds, stream, a);
+  }
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
 static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, int64_t c_block,
                     float* out, float* aux, int aux_mode, int64_t B, void* stream) {
   if (!m || !in || !c || B < 0 || c_block < 1) return CNF_ERR_INVALID;
   if (!out && !aux) return CNF_ERR_INVALID;
   if (!m->params_set) return CNF_ERR_INVALID;
   if (B == 0) return CNF_OK;
+  {
+    const int r = run_flow_pwl(m, to_base, in, c, c_block, out, aux, aux_mode, B, (hipStream_t)stream);
+    if (r != CNF_ERR_UNSUPPORTED) return r;
+  }
   FlowArgs a;
   a.m = model_args(m);
   a.in = in; a.c = c; a.out = out; a.aux = aux;

@@ -96,8 +96,13 @@ class FlowEngine:
 
   def set_mfma(self, on: bool) -> None:
     """MFMA (v_mfma_f32_16x16x4_f32) conditioner where available (hidden 16,
-    5 bins, fast math) -- the default -- or the packed-VALU conditioner."""
+    5 bins, fast math), or the packed-VALU conditioner (the default)."""
     _capi.check(self.lib.cnf_model_set_mfma(self._h, 1 if on else 0), "cnf_model_set_mfma")
+
+  def set_pwl(self, mode: int) -> None:
+    """Piecewise-linear conditioner tables (dim 2, slice-uniform condition):
+    1 = for large launches (default), 2 = whenever they apply, 0 = never."""
+    _capi.check(self.lib.cnf_model_set_pwl(self._h, int(mode)), "cnf_model_set_pwl")
 
   def set_samples_per_lane(self, spl: int) -> None:
     """0: chosen by batch size (default); 1 / 2: force the one-sample or the

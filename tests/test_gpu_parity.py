@@ -70,19 +70,21 @@ GOLDEN = {
 }
 
 
-@pytest.mark.parametrize("variant", ["mfma2", "mfma1", "packed2", "fast1", "ocml1"])
+@pytest.mark.parametrize("variant", ["mfma2", "mfma1", "packed2", "fast1", "ocml1", "pwl"])
 @pytest.mark.parametrize("name", sorted(GOLDEN))
 def test_golden_vectors(golden_dir, dev, name, variant):
   """Every kernel variant: MFMA conditioner with two / one samples per lane
   (the default for the reference's 16-wide network), packed-VALU conditioner,
-  one sample per lane, and ocml expf/logf + IEEE division instead of the
-  hardware transcendentals."""
+  one sample per lane, ocml expf/logf + IEEE division instead of the hardware
+  transcendentals, and the piecewise-linear conditioner tables (dim 2 with a
+  uniform condition; every other case must fall through to the MLP kernel)."""
   fcfg, _ = _cfg_pair(**GOLDEN[name])
   g = np.load(os.path.join(golden_dir, name))
   eng = _engine(fcfg, g["params"], dev)
   eng.set_fast_math(variant != "ocml1")
   eng.set_mfma(variant.startswith("mfma"))       # only takes effect for hidden 16 / 5 bins
   eng.set_samples_per_lane(2 if variant.endswith("2") else 1)
+  eng.set_pwl(2 if variant == "pwl" else 0)
   x = _t(g["noise"], dev)
   for tag, c in (("u", g["c_uniform"]), ("p", g["c_per"])):
     ct = _t(c, dev)
@@ -139,6 +141,56 @@ def test_config2_batch_65536_vs_oracle(dev, params_kind, t, spl, mfma):
   assert elpd.max() <= TOL_LP_DATA_MAX and np.quantile(elpd, 0.999) <= TOL_LP_DATA_P999
 
 
+@pytest.mark.parametrize("params_kind", ["zeros", "random", "first_only"])
+def test_config2_piecewise_linear_tables(dev, params_kind):
+  """The dim-2 fast path (cnf_pwl.h): conditioner read from exact piecewise-
+  linear tables built per (slice, layer).  Same bars as the MLP kernels, on
+  slices of ragged (even) length with a partial last slice; `zeros` and
+  `first_only` (all conditioner weights zero) are the degenerate one-piece
+  tables."""
+  import oracle
+  fcfg, ocfg = _cfg_pair(D=2)
+  rng = np.random.default_rng(11)
+  n = oracle.param_count(ocfg)
+  params = np.zeros(n)
+  if params_kind == "random":
+    params = rng.normal(0, 0.2, n).astype(np.float32).astype(np.float64)
+  elif params_kind == "first_only":
+    params[:16] = rng.normal(0, 0.5, 16).astype(np.float32)
+  S, Bs = 7, 9998                      # 7 slices of 9 998 = 4 tiles of 2 048 + a partial one
+  B = S * Bs - 4000                    # the last slice is short
+  noise = rng.normal(size=(S * Bs, 2)).astype(np.float32)
+  noise[0] = [11.0, -12.5]             # linear tails
+  noise[1] = [-30.0, 40.0]             # outside the coarse grid of the tables
+  ts = np.linspace(0.0, 1.0, S)
+  eng = _engine(fcfg, params, dev)
+  eng.set_pwl(2)
+  c_host = np.repeat(ts, Bs)
+  y, lp = eng.sample_logprob(_t(noise, dev), _t(ts, dev))
+  y_ref, lp_ref = oracle.sample_logprob(ocfg, params, noise.astype(np.float64), c_host)
+  ey, elp = _err(y, y_ref), _err(lp, lp_ref)
+  print(f"\n[pwl {params_kind}] max|dy|={ey.max():.2e} max|dlogp|={elp.max():.2e}")
+  assert ey.max() <= TOL_Y and elp.max() <= TOL_LP_SAMPLE
+  # the short batch: c given per slice with an explicit c_block through the generic per-sample form
+  yb, lpb = eng.sample_logprob(_t(noise[:B], dev), _t(c_host[:B], dev)[:, None])      # per sample: MLP kernel
+  assert _err(yb, y_ref[:B]).max() <= TOL_Y and _err(lpb, lp_ref[:B]).max() <= TOL_LP_SAMPLE
+  # data -> base through the tables, single condition, ragged odd batch
+  Bo = 50001
+  y_in = y_ref[:Bo].astype(np.float32)
+  xb_ref, ildj_ref = oracle.inverse_logdet(ocfg, params, y_in.astype(np.float64), [0.37])
+  lp_ref1 = oracle.log_prob(ocfg, params, y_in.astype(np.float64), [0.37])
+  xb, ildj = eng.inverse_logdet(_t(y_in, dev), torch.tensor([0.37], device=dev))
+  ex = _err(xb, xb_ref)
+  # `first_only`/`random` samples in the far tail ( |y| = 30, 40 ) carry the fp32 floor of their magnitude
+  assert ex.max() <= TOL_Y and _err(ildj, ildj_ref).max() <= 2 * TOL_LD
+  elpd = _err(eng.log_prob(_t(y_in, dev), torch.tensor([0.37], device=dev)), lp_ref1)
+  assert elpd.max() <= TOL_LP_DATA_MAX and np.quantile(elpd, 0.999) <= TOL_LP_DATA_P999
+  # and the tables agree with the MLP kernel far below the oracle tolerance
+  eng.set_pwl(0)
+  y0, lp0 = eng.sample_logprob(_t(noise, dev), _t(ts, dev))
+  assert (y0 - y).abs().max().item() <= 1e-5 and (lp0 - lp).abs().max().item() <= 1e-5
+
+
 def test_dim10_batch_vs_oracle(dev):
   """BASELINE config 4 shape: D=10 (per-GPU shard 32 768), N(0, 0.12^2) params."""
   import oracle
@@ -155,14 +207,17 @@ def test_dim10_batch_vs_oracle(dev):
   assert _err(lp, lp_ref).max() <= 2e-5      # 20 splines summed instead of 4
 
 
-def test_wild_params_no_worse_than_fp32_port(dev, golden_dir):
-  """SURVEY.md 8(d) cfg 2 (ii) literal: N(0, 0.5^2) on every tensor, seed 42."""
+@pytest.mark.parametrize("pwl", [0, 2], ids=["mlp", "pwl"])
+def test_wild_params_no_worse_than_fp32_port(dev, golden_dir, pwl):
+  """SURVEY.md 8(d) cfg 2 (ii) literal: N(0, 0.5^2) on every tensor, seed 42
+  (with the piecewise-linear tables too: many breakpoints inside the range)."""
   import oracle
   fcfg, ocfg = _cfg_pair(D=2)
   rng = np.random.default_rng(42)
   params = rng.normal(0, 0.5, oracle.param_count(ocfg)).astype(np.float32)
   noise = rng.normal(size=(65536, 2)).astype(np.float32)
   eng = _engine(fcfg, params, dev)
+  eng.set_pwl(pwl)
   _, lp = eng.sample_logprob(_t(noise, dev), torch.tensor([0.5], device=dev))
   _, lp64 = oracle.sample_logprob(ocfg, params.astype(np.float64), noise.astype(np.float64), [0.5])
   _, lp32 = oracle.sample_logprob(ocfg, params, noise, [0.5], dtype=np.float32)
