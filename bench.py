@@ -48,8 +48,8 @@ PEAK_HBM_GBS = 8000.0
 def parse_args():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=16384)
-  ap.add_argument("--warmup", type=int, default=1024)
+  ap.add_argument("--steps", type=int, default=65536)
+  ap.add_argument("--warmup", type=int, default=4096)
   ap.add_argument("--slices-per-launch", type=int, default=256)
   ap.add_argument("--param-scale", type=float, default=0.2)
   ap.add_argument("--shard", choices=("slices", "samples"), default="slices",

@@ -1,6 +1,8 @@
 // cnf_common.h -- structs shared by the translation units of libcnf_ot_amd.so
 // (cnf_flow.hip: forward kernels + C ABI; cnf_grad.hip: backward + Adam).
 #pragma once
+#include <mutex>
+#include <unordered_map>
 
 #include "cnf_device.h"
 #include "../../include/cnf_ot_amd.h"
@@ -75,8 +77,11 @@ struct CnfModel {
   float* grad_slabs;      // per-wave gradient slabs (cnf_grad_enable), or null
   int64_t grad_max_blocks;
   int use_pwl;            // 1: piecewise-linear conditioner tables at dim 2 (cnf_pwl.h)
-  float* pwl_tables;      // [pwl_slices][L][PWL_TBL] workspace, grown on demand
-  int64_t pwl_slices;
+  // table workspaces [slices][L][PWL_TBL], one per stream that has run the table path (so calls on
+  // different streams never share one), grown on demand
+  struct PwlWorkspace { float* tables; int64_t slices; };
+  std::mutex pwl_mu;
+  std::unordered_map<void*, PwlWorkspace> pwl_ws;
 };
 
 #ifdef CNF_MINIMAL_CONFIGS   /* faster builds while iterating on the kernels */

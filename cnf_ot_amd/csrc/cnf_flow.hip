@@ -687,9 +687,8 @@ extern "C" int cnf_model_create(const CnfConfig* cfg, CnfModel** out) {
   *out = nullptr;
   if (!config_valid(cfg)) return CNF_ERR_INVALID;
   if (!cnf_config_supported(cfg)) return CNF_ERR_UNSUPPORTED;
-  CnfModel* m = new (std::nothrow) CnfModel;
+  CnfModel* m = new (std::nothrow) CnfModel();       // value-initialised: scalars and pointers start at zero
   if (!m) return CNF_ERR_NOMEM;
-  memset(m, 0, sizeof(*m));
   m->cfg = *cfg;
   const int K = cfg->num_bins, P = 3 * K + 1;
   m->n_params = cnf_param_count(cfg);
@@ -709,8 +708,6 @@ extern "C" int cnf_model_create(const CnfConfig* cfg, CnfModel** out) {
   // and at equal peak rate the packed-VALU conditioner is 4-5 % faster.
   m->use_mfma = 0;
   m->use_pwl = 1;
-  m->pwl_tables = nullptr;
-  m->pwl_slices = 0;
   // (D = 1 would need 2^32: encoded as 0, tile_load/tile_store take s = e)
   m->div_magic = cfg->dim == 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + (uint64_t)cfg->dim - 1) / (uint64_t)cfg->dim);
   m->per_layer_q = 0; m->mfma_off = 0;
@@ -736,7 +733,7 @@ extern "C" void cnf_model_destroy(CnfModel* m) {
   if (!m) return;
   if (m->prep) (void)hipFree(m->prep);
   if (m->grad_slabs) (void)hipFree(m->grad_slabs);
-  if (m->pwl_tables) (void)hipFree(m->pwl_tables);
+  for (auto& kv : m->pwl_ws) if (kv.second.tables) (void)hipFree(kv.second.tables);
   delete m;
 }
 
@@ -856,23 +853,29 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
   // the tables cost one small kernel per launch: worth it once every CU has a tile,
   // and only while a slice is long enough to amortise building its tables
   if (m->use_pwl == 1 && (total < m->num_cus || slice_len < 4 * PWL_TS)) return CNF_ERR_UNSUPPORTED;
-  if (m->pwl_slices < n_slices) {
-    // grow the workspace (the only allocation in a compute entry point; reserve with a first call at the
-    // largest slice count before capturing a graph)
-    if (m->pwl_tables) {
-      if (hipStreamSynchronize(stream) != hipSuccess) return CNF_ERR_HIP;
-      (void)hipFree(m->pwl_tables);
-      m->pwl_tables = nullptr; m->pwl_slices = 0;
+  float* tables = nullptr;
+  {
+    // this stream's workspace; grown when a call has more slices than any before on the stream (the only
+    // allocation a compute entry point can make: warm up once before capturing a graph)
+    std::lock_guard<std::mutex> lock(m->pwl_mu);
+    CnfModel::PwlWorkspace& ws = m->pwl_ws[(void*)stream];          // value-initialised on first use
+    if (ws.slices < n_slices) {
+      if (ws.tables) {
+        if (hipStreamSynchronize(stream) != hipSuccess) return CNF_ERR_HIP;
+        (void)hipFree(ws.tables);
+        ws.tables = nullptr; ws.slices = 0;
+      }
+      if (hipMalloc((void**)&ws.tables, sizeof(float) * (size_t)n_slices * L * cnf::PWL_TBL) != hipSuccess) return CNF_ERR_NOMEM;
+      ws.slices = n_slices;
     }
-    if (hipMalloc((void**)&m->pwl_tables, sizeof(float) * (size_t)n_slices * L * cnf::PWL_TBL) != hipSuccess) return CNF_ERR_HIP;
-    m->pwl_slices = n_slices;
+    tables = ws.tables;
   }
   hipLaunchKernelGGL(cnf::pwl_build_kernel, dim3((unsigned)(n_slices * L)), dim3(512), 0, stream,
                      (const float*)(m->prep + cnf::hdr_floats(5)), m->per_layer, c, 0.0f, L,
-                     log(exp(1.0 - (double)m->cfg.min_knot_slope) - 1.0), m->pwl_tables);
+                     log(exp(1.0 - (double)m->cfg.min_knot_slope) - 1.0), tables);
   cnf::PwlArgs a;
   a.m = model_args(m);
-  a.in = in; a.out = out; a.aux = aux; a.tables = m->pwl_tables;
+  a.in = in; a.out = out; a.aux = aux; a.tables = tables;
   a.B = B; a.slice_len = slice_len;
   a.n_slices = (int32_t)n_slices; a.tiles_per_slice = (int32_t)tps; a.aux_mode = aux_mode;
   if (pwl_min_lds > lds) lds = pwl_min_lds;

@@ -14,7 +14,11 @@
  *    contiguous row-major float32 unless a parameter says otherwise;
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream);
  *    every compute entry point only enqueues work on that stream: no
- *    allocation, no synchronisation, graph-capturable;
+ *    allocation, no synchronisation, graph-capturable.  One exception: large
+ *    dim-2 flow calls with a slice-uniform condition build per-slice conditioner
+ *    tables into a workspace kept per (model, stream); it is allocated by the
+ *    first such call on a stream and re-allocated when a call has more slices
+ *    than any before -- make one warm-up call before capturing a graph;
  *  - return value: 0 on success, negative CNF_ERR_* otherwise; nothing throws;
  *  - a CnfModel may be used from several host threads as long as each uses its
  *    own stream and nobody calls cnf_model_set_params concurrently.

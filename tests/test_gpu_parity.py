@@ -224,6 +224,32 @@ def test_config2_piecewise_linear_tables(dev, params_kind):
   assert (y0 - y).abs().max().item() <= 1e-5 and (lp0 - lp).abs().max().item() <= 1e-5
 
 
+def test_table_path_on_two_streams(dev):
+  """The conditioner tables live in a workspace per (model, stream): calls of
+  one model issued on two streams, with different slice counts (one grows its
+  workspace mid-way), give the single-stream results."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  cfg = FlowConfig(dim=2)
+  eng = FlowEngine(cfg, dev).load(Params.random(cfg, 0.2, seed=5, device=dev))
+  eng.set_pwl(2)
+  Bs = 4096
+  jobs = []
+  for i, S in enumerate((3, 9, 5, 17)):
+    x = eng.normal(100 + i, S * Bs)
+    t = torch.linspace(0.1, 0.9, S, device=dev)
+    jobs.append((x, t, eng.sample_logprob(x, t)))
+  torch.cuda.synchronize()
+  streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+  outs = []
+  for rep in range(3):
+    for i, (x, t, _) in enumerate(jobs):
+      with torch.cuda.stream(streams[i % 2]):
+        outs.append((i, eng.sample_logprob(x, t)))
+  torch.cuda.synchronize()
+  for i, (y, lp) in outs:
+    assert torch.equal(y, jobs[i][2][0]) and torch.equal(lp, jobs[i][2][1])
+
+
 def test_dim10_batch_vs_oracle(dev):
   """BASELINE config 4 shape: D=10 (per-GPU shard 32 768), N(0, 0.12^2) params."""
   import oracle
