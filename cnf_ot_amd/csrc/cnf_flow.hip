@@ -331,12 +331,48 @@ struct PwlArgs {
   int32_t n_slices, tiles_per_slice, aux_mode;
 };
 
+// Stage the L tables of (set, slice) into LDS: header arrays + the rows in use, at most PWL_LROWS.
+__device__ __forceinline__ void pwl_stage(float* tbl, const float* __restrict__ g0, int L, int tid, int nthreads) {
+  for (int l = 0; l < L; ++l) {
+    const float* g = g0 + (int64_t)l * PWL_TBL;
+    const int n = __float_as_int(g[PWL_N_SLOT]);                       // pieces 0 .. n
+    const int rows = n + 1 < PWL_LROWS ? n + 1 : PWL_LROWS;
+    const f4* src = reinterpret_cast<const f4*>(g);
+    f4* dst = reinterpret_cast<f4*>(tbl + l * PWL_LTBL);
+    for (int i = tid; i < (PWL_OFF_PIECE + rows * 2 * PWL_P) / 4; i += nthreads) dst[i] = src[i];
+  }
+}
+
+// The dim-2 flow on one sample pair held in registers, conditioner from the tables (`tbl`: the L
+// tables in LDS, `gtbl`: the same in global memory for rows past the LDS window).  In place;
+// returns the accumulated log|det J| of the direction.
+template <int K, bool TO_BASE, bool FAST>
+__device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, const float* __restrict__ gtbl,
+                                            int L, const SplineConsts& sc, v2f& u0, v2f& u1) {
+  constexpr bool INV = !TO_BASE;
+  v2f acc = splat<v2f>(0.0f);
+  for (int step = 0; step < L; ++step) {
+    const int l = TO_BASE ? L - 1 - step : step;
+    const bool odd = l & 1;                     // flows.py:141-143 perms
+    const v2f uf = odd ? u1 : u0, uo = odd ? u0 : u1;
+    v2f of, oo, ld;
+    table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld);
+    acc += ld;
+    v2f th[PWL_P];
+    pwl_eval(tbl + l * PWL_LTBL, gtbl + (int64_t)l * PWL_TBL, TO_BASE ? of : uf, th);
+    cond_spline_masked<K, INV, FAST>(th, uo, sc, oo, ld);
+    acc += ld;
+    u0 = odd ? oo : of;
+    u1 = odd ? of : oo;
+  }
+  return acc;
+}
+
 template <int K, bool TO_BASE, bool FAST>
 __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs a) {
   const int PWL_THREADS = blockDim.x, PWL_TS = 2 * PWL_THREADS;
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   constexpr int HDR = (hdr_floats(K) + 3) & ~3;
-  constexpr bool INV = !TO_BASE;
   float* tab = lds_raw;
   float* tbl = lds_raw + HDR;
   const int tid = threadIdx.x;
@@ -353,14 +389,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
     const int slice = tile / a.tiles_per_slice;
     if (slice != cur) {
       __syncthreads();
-      for (int l = 0; l < L; ++l) {
-        const float* g = a.tables + ((int64_t)slice * L + l) * PWL_TBL;
-        const int n = __float_as_int(g[PWL_N_SLOT]);                       // pieces 0 .. n
-        const int rows = n + 1 < PWL_LROWS ? n + 1 : PWL_LROWS;
-        const f4* src = reinterpret_cast<const f4*>(g);
-        f4* dst = reinterpret_cast<f4*>(tbl + l * PWL_LTBL);
-        for (int i = tid; i < (PWL_OFF_PIECE + rows * 2 * PWL_P) / 4; i += PWL_THREADS) dst[i] = src[i];
-      }
+      pwl_stage(tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, tid, PWL_THREADS);
       cur = slice;
       __syncthreads();
     }
@@ -376,21 +405,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
 
     v2f base = splat<v2f>(0.0f);
     if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = (u0 * u0 + u1 * u1) * -0.5f - (float)(2 * HALF_LOG_2PI);
-    v2f acc = splat<v2f>(0.0f);
-    for (int step = 0; step < L; ++step) {
-      const int l = TO_BASE ? L - 1 - step : step;
-      const bool odd = l & 1;                     // flows.py:141-143 perms
-      const v2f uf = odd ? u1 : u0, uo = odd ? u0 : u1;
-      v2f of, oo, ld;
-      table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld);
-      acc += ld;
-      v2f th[PWL_P];
-      pwl_eval(tbl + l * PWL_LTBL, a.tables + ((int64_t)slice * L + l) * PWL_TBL, TO_BASE ? of : uf, th);
-      cond_spline_masked<K, INV, FAST>(th, uo, sc, oo, ld);
-      acc += ld;
-      u0 = odd ? oo : of;
-      u1 = odd ? of : oo;
-    }
+    const v2f acc = flow2_tables<K, TO_BASE, FAST>(tab, tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, sc, u0, u1);
     if (a.aux) {
       v2f r = acc;
       if (a.aux_mode == AUX_LOGPROB)
@@ -585,6 +600,171 @@ __global__ __launch_bounds__(TILE, 2) void loss_kernel(const LossArgs a) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(a.sums + slice, (double)part);
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// loss_pwl_kernel: the fused loss terms at dim 2 on the conditioner tables.
+// Same terms and arithmetic as loss_kernel; a sample pair lives in registers,
+// the passes of a term use up to three table sets (conditions t - dt/2,
+// t + dt/2, t), each L x 21 KB in LDS.  Base noise comes from `pts` or from the
+// Philox stream (one counter block = the pair's four normals when aligned).
+// ---------------------------------------------------------------------------
+struct LossPwlArgs {
+  ModelArgs m;
+  CnfLossSpec spec;
+  const float* pts;
+  const float* t;
+  double* sums;
+  const float* tables;        // [n_sets][n_slices][L][PWL_TBL]
+  int64_t B, n_slices, pts_slice_stride;
+  uint64_t seed;
+  int64_t first_sample;
+  int32_t n_sets, tiles_per_slice;
+};
+
+__device__ __forceinline__ float normal_at(uint64_t seed, uint64_t e) {     // element e of the cnf_fill_normal stream
+  const uint64_t blk = e >> 2;
+  uint32_t u[4];
+  philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), u);
+  const int p = (int)(e & 3) >> 1;
+  const float u1 = (float)((u[2 * p] >> 8) + 1u) * (1.0f / 16777216.0f);
+  const float u2 = (float)(u[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
+  const float rad = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincospif(2.0f * u2, &sn, &cs);
+  return (e & 1) == 0 ? rad * cs : rad * sn;
+}
+
+template <int K, bool FAST>
+__global__ __launch_bounds__(PWL_MAX_THREADS) void loss_pwl_kernel(const LossPwlArgs a) {
+  using M = Math<FAST>;
+  typedef v2f T;
+  const int NT = blockDim.x, TS = 2 * NT;
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  constexpr int HDR = (hdr_floats(K) + 3) & ~3;
+  const int tid = threadIdx.x;
+  const int L = a.m.L;
+  float* tab = lds_raw;
+  float* tbl = lds_raw + HDR;                               // n_sets x L tables
+  float* R = tbl + a.n_sets * L * PWL_LTBL;                 // 2 x TS scratch columns (potential_of / drift_of read LDS columns)
+  for (int i = tid; i < hdr_floats(K); i += NT) tab[i] = table_of<float>(a.m)[i];
+  const SplineConsts& sc = sc_of<float>(a.m);
+  const int kind = a.spec.kind;
+  const bool kin = kind <= CNF_TERM_FLOW_MATCHING;
+  const float dt = a.spec.dt, dx = a.spec.dx;
+  const int64_t set_stride = a.n_slices * L * (int64_t)PWL_TBL;
+  const int col = 2 * tid;
+
+  const int total = (int)a.n_slices * a.tiles_per_slice;
+  const int per_block = (total + gridDim.x - 1) / gridDim.x;
+  const int t0 = blockIdx.x * per_block;
+  const int t1 = t0 + per_block < total ? t0 + per_block : total;
+  int cur = -1;
+  for (int tile = t0; tile < t1; ++tile) {
+    const int slice = tile / a.tiles_per_slice;
+    __syncthreads();                                        // the previous tile is done with R (and the tables)
+    if (slice != cur) {
+      for (int s = 0; s < a.n_sets; ++s)
+        pwl_stage(tbl + s * L * PWL_LTBL, a.tables + s * set_stride + (int64_t)slice * L * PWL_TBL, L, tid, NT);
+      cur = slice;
+      __syncthreads();
+    }
+    const float* gslice = a.tables + (int64_t)slice * L * PWL_TBL;
+    const int64_t j = (int64_t)(tile - slice * a.tiles_per_slice) * TS + col;
+    const bool v0 = j < a.B, v1 = j + 1 < a.B;
+    const float t = a.t[slice];
+    // the pair's points: x = (n0.x, n1.x), y = (n0.y, n1.y)
+    f4 x = {0.f, 0.f, 0.f, 0.f};
+    const int64_t g = slice * a.pts_slice_stride + j;       // sample index in pts / offset in the stream
+    if (a.pts) {
+      const float* src = a.pts + 2 * g;
+      if (v1 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) x = *reinterpret_cast<const f4*>(src);
+      else { if (v0) { x[0] = src[0]; x[1] = src[1]; } if (v1) { x[2] = src[2]; x[3] = src[3]; } }
+    } else {
+      const uint64_t e0 = (uint64_t)(a.first_sample + g) * 2u;
+      if ((e0 & 3) == 0) {                                  // one Philox block holds the pair
+        uint32_t u[4];
+        philox4x32((uint32_t)(e0 >> 2), (uint32_t)(e0 >> 34), 0u, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), u);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const float u1 = (float)((u[2 * p] >> 8) + 1u) * (1.0f / 16777216.0f);
+          const float u2 = (float)(u[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
+          const float rad = sqrtf(-2.0f * logf(u1));
+          float sn, cs;
+          sincospif(2.0f * u2, &sn, &cs);
+          x[2 * p] = rad * cs;
+          x[2 * p + 1] = rad * sn;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = normal_at(a.seed, e0 + q);
+      }
+      if (!v0) { x[0] = 0.f; x[1] = 0.f; }
+      if (!v1) { x[2] = 0.f; x[3] = 0.f; }
+    }
+    const T n0 = {x[0], x[2]}, n1 = {x[1], x[3]};
+
+    T acc = splat<T>(0.0f);
+    const int n_fwd = kind == CNF_TERM_NEG_LOGPROB ? 0 : (kind == CNF_TERM_KINETIC ? 2 : (kin ? 3 : 1));
+    T fldj = splat<T>(0.0f);
+    T y0 = n0, y1 = n1, va = splat<T>(0.0f), vb = splat<T>(0.0f);     // (va, vb): r1, then the velocity
+    for (int p = 0; p < n_fwd; ++p) {                                  // set p: conditions t - dt/2, t + dt/2, t (kin) or t
+      y0 = n0; y1 = n1;
+      fldj = flow2_tables<K, false, FAST>(tab, tbl + p * L * PWL_LTBL, gslice + p * set_stride, L, sc, y0, y1);
+      if (kin) {
+        if (p == 0) { va = y0; vb = y1; }
+        else if (p == 1) { const float inv_dt = 1.0f / dt; va = (y0 - va) * inv_dt; vb = (y1 - vb) * inv_dt; }
+      }
+    }
+    const int tset = kin ? 2 : 0;                                       // the set of condition t
+    if (kind == CNF_TERM_KINETIC) {
+      acc = vfma(va, va, vb * vb);
+    } else if (kind == CNF_TERM_POTENTIAL) {
+      lds_put(R + col, 0, TS, y0); lds_put(R + col, 1, TS, y1);
+      acc = potential_of<FAST, T>(R + col, 2, TS, a.spec.subtype, a.spec.a);
+    } else if (kind == CNF_TERM_REVERSE_KL) {
+      const T lp = vfma(n0 * -0.5f, n0, n1 * n1 * -0.5f) - (float)(2 * HALF_LOG_2PI) - fldj;
+      const T s2 = vfma(y0, y0, y1 * y1);
+      // log(N(y;0,vs I) ws + N(y;0,vt I) wt) as a log-sum-exp (applications.py:136-163)
+      const float Tt = a.spec.T, vs = 2.0f / a.spec.beta * (Tt + 1.0f), vt = 2.0f / a.spec.beta;
+      const float ws = (Tt - t) / Tt, wt = t / Tt;
+      const float ls = -logf(6.283185307179586f * vs), lt = -logf(6.283185307179586f * vt);    // -0.5 D log(2 pi v), D = 2
+      const T as = vfma(s2, splat<T>(-0.5f / vs), splat<T>(ls));
+      const T at = vfma(s2, splat<T>(-0.5f / vt), splat<T>(lt));
+      const T mx = vmax(as, at);
+      const T mix = M::exp(as - mx) * ws + M::exp(at - mx) * wt;
+      acc = lp - (mx + M::log(mix));
+    }
+    // data->base passes: NEG_LOGPROB (one, on the points themselves) or the central differences of
+    // log_prob at r3 +- dx/2 e_d (applications.py:264-273); r3 = (y0, y1) of the pass at condition t
+    const bool neg = kind == CNF_TERM_NEG_LOGPROB;
+    const int n_tb = neg ? 1 : ((kind == CNF_TERM_KINETIC_SCORE || kind == CNF_TERM_FLOW_MATCHING) ? 4 : 0);
+    if (kind == CNF_TERM_FLOW_MATCHING) { lds_put(R + col, 0, TS, y0); lds_put(R + col, 1, TS, y1); }
+    T lp0 = splat<T>(0.0f);
+    for (int e = 0; e < n_tb; ++e) {
+      const int d = e >> 1, sgn = e & 1;
+      T u0 = neg ? n0 : y0, u1 = neg ? n1 : y1;
+      if (!neg) {
+        const float h = sgn == 0 ? 0.5f * dx : -0.5f * dx;
+        if (d == 0) u0 = u0 + h; else u1 = u1 + h;
+      }
+      const T ildj = flow2_tables<K, true, FAST>(tab, tbl + tset * L * PWL_LTBL, gslice + tset * set_stride, L, sc, u0, u1);
+      const T lp = vfma(u0 * -0.5f, u0, u1 * u1 * -0.5f) - (float)(2 * HALF_LOG_2PI) + ildj;
+      if (neg) acc = -lp;
+      else if (sgn == 0) lp0 = lp;
+      else {
+        T v = vfma((lp0 - lp) * (1.0f / dx), splat<T>(a.spec.coef), d == 0 ? va : vb);
+        if (kind == CNF_TERM_FLOW_MATCHING) v -= drift_of<T>(R + col, d, 2, TS, a.spec.subtype, a.spec.a);
+        acc = vfma(v, v, acc);
+      }
+    }
+    // tile reduction: lanes -> wave (shuffles) -> one double atomic per wave
+    float part = (v0 ? acc.x : 0.0f) + (v1 ? acc.y : 0.0f);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if ((tid & 63) == 0) atomicAdd(a.sums + slice, (double)part);
   }
 }
 
@@ -823,16 +1003,39 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
   return CNF_ERR_UNSUPPORTED;
 }
 
+// This stream's table workspace, large enough for `n_slices` slices (x L tables); grown when a call needs
+// more than any before on the stream (the only allocation a compute entry point can make: warm up once
+// before capturing a graph).
+static int pwl_workspace(CnfModel* m, hipStream_t stream, int64_t n_slices, float** out) {
+  std::lock_guard<std::mutex> lock(m->pwl_mu);
+  CnfModel::PwlWorkspace& ws = m->pwl_ws[(void*)stream];          // value-initialised on first use
+  if (ws.slices < n_slices) {
+    if (ws.tables) {
+      if (hipStreamSynchronize(stream) != hipSuccess) return CNF_ERR_HIP;
+      (void)hipFree(ws.tables);
+      ws.tables = nullptr; ws.slices = 0;
+    }
+    if (hipMalloc((void**)&ws.tables, sizeof(float) * (size_t)n_slices * m->cfg.num_layers * cnf::PWL_TBL) != hipSuccess)
+      return CNF_ERR_NOMEM;
+    ws.slices = n_slices;
+  }
+  *out = ws.tables;
+  return CNF_OK;
+}
+
+static bool pwl_config_ok(const CnfModel* m) {
+  const CnfConfig& g = m->cfg;
+  return m->use_pwl && m->fast_math && g.dim == 2 && g.hidden_size == cnf::PWL_H && g.num_bins == 5 &&
+         g.mlp_num_layers == 2;
+}
+
 // The piecewise-linear path (cnf_pwl.h): dim 2, H = 16, K = 5, two MLP layers, a condition that is
 // uniform over slices of even length, 16-byte aligned points.  Returns CNF_ERR_UNSUPPORTED when the
 // launch does not qualify (the caller then runs the MLP kernel).
 static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float* c, int64_t c_block,
                         float* out, float* aux, int aux_mode, int64_t B, hipStream_t stream) {
-  const CnfConfig& g = m->cfg;
-  if (!m->use_pwl || !m->fast_math || g.dim != 2 || g.hidden_size != cnf::PWL_H || g.num_bins != 5 ||
-      g.mlp_num_layers != 2)
-    return CNF_ERR_UNSUPPORTED;
-  const int L = g.num_layers;
+  if (!pwl_config_ok(m)) return CNF_ERR_UNSUPPORTED;
+  const int L = m->cfg.num_layers;
   size_t lds = (size_t)(((cnf::hdr_floats(5) + 3) & ~3) + L * cnf::PWL_LTBL) * sizeof(float);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
   const int64_t slice_len = c_block < B ? c_block : B;
@@ -855,20 +1058,8 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
   if (m->use_pwl == 1 && (total < m->num_cus || slice_len < 4 * PWL_TS)) return CNF_ERR_UNSUPPORTED;
   float* tables = nullptr;
   {
-    // this stream's workspace; grown when a call has more slices than any before on the stream (the only
-    // allocation a compute entry point can make: warm up once before capturing a graph)
-    std::lock_guard<std::mutex> lock(m->pwl_mu);
-    CnfModel::PwlWorkspace& ws = m->pwl_ws[(void*)stream];          // value-initialised on first use
-    if (ws.slices < n_slices) {
-      if (ws.tables) {
-        if (hipStreamSynchronize(stream) != hipSuccess) return CNF_ERR_HIP;
-        (void)hipFree(ws.tables);
-        ws.tables = nullptr; ws.slices = 0;
-      }
-      if (hipMalloc((void**)&ws.tables, sizeof(float) * (size_t)n_slices * L * cnf::PWL_TBL) != hipSuccess) return CNF_ERR_NOMEM;
-      ws.slices = n_slices;
-    }
-    tables = ws.tables;
+    const int r = pwl_workspace(m, stream, n_slices, &tables);
+    if (r != CNF_OK) return r;
   }
   hipLaunchKernelGGL(cnf::pwl_build_kernel, dim3((unsigned)(n_slices * L)), dim3(512), 0, stream,
                      (const float*)(m->prep + cnf::hdr_floats(5)), m->per_layer, c, 0.0f, L,
@@ -954,6 +1145,47 @@ extern "C" int cnf_fill_normal(uint64_t seed, uint64_t first_element, int64_t n,
 }
 
 
+// The loss terms on the conditioner tables (loss_pwl_kernel): same qualification as run_flow_pwl.
+static int loss_terms_pwl(CnfModel* m, const CnfLossSpec* spec, const float* pts, int64_t slice_stride,
+                          uint64_t seed, int64_t first_sample, const float* t, int64_t n_slices, int64_t B,
+                          double* sums, hipStream_t stream) {
+  if (!pwl_config_ok(m)) return CNF_ERR_UNSUPPORTED;
+  const int L = m->cfg.num_layers;
+  const int kind = spec->kind;
+  const bool kin = kind <= CNF_TERM_FLOW_MATCHING;
+  const int n_sets = kind == CNF_TERM_KINETIC ? 2 : (kin ? 3 : 1);
+  const int threads = cnf::PWL_MAX_THREADS;
+  const int64_t ts = 2 * threads;
+  const size_t lds = (size_t)(((cnf::hdr_floats(5) + 3) & ~3) + n_sets * L * cnf::PWL_LTBL + 2 * ts) * sizeof(float);
+  if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
+  const int64_t tps = (B + ts - 1) / ts;
+  const int64_t total = n_slices * tps;
+  if (total > (1 << 30)) return CNF_ERR_UNSUPPORTED;
+  if (m->use_pwl == 1 && (total < m->num_cus || B < 4 * ts)) return CNF_ERR_UNSUPPORTED;
+  float* tables = nullptr;
+  {
+    const int r = pwl_workspace(m, stream, n_slices * n_sets, &tables);
+    if (r != CNF_OK) return r;
+  }
+  const double sp_offset = log(exp(1.0 - (double)m->cfg.min_knot_slope) - 1.0);
+  const int64_t set_stride = n_slices * L * (int64_t)cnf::PWL_TBL;
+  for (int s = 0; s < n_sets; ++s) {          // conditions t - dt/2, t + dt/2, t (kinetic kinds) or t
+    const float off = !kin ? 0.0f : (s == 0 ? -0.5f * spec->dt : (s == 1 ? 0.5f * spec->dt : 0.0f));
+    hipLaunchKernelGGL(cnf::pwl_build_kernel, dim3((unsigned)(n_slices * L)), dim3(512), 0, stream,
+                       (const float*)(m->prep + cnf::hdr_floats(5)), m->per_layer, t, off, L, sp_offset,
+                       tables + s * set_stride);
+  }
+  cnf::LossPwlArgs a;
+  a.m = model_args(m); a.spec = *spec; a.pts = pts; a.t = t; a.sums = sums; a.tables = tables;
+  a.B = B; a.n_slices = n_slices; a.pts_slice_stride = slice_stride;
+  a.seed = seed; a.first_sample = first_sample;
+  a.n_sets = n_sets; a.tiles_per_slice = (int32_t)tps;
+  const int64_t grid = total < m->num_cus ? total : m->num_cus;
+  if (!ensure_lds(cnf::loss_pwl_kernel<5, true>, lds)) return CNF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((cnf::loss_pwl_kernel<5, true>), dim3((unsigned)grid), dim3(threads), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
 static int loss_terms_impl(CnfModel* m, const CnfLossSpec* spec, const float* pts, int64_t slice_stride,
                            uint64_t seed, int64_t first_sample, const float* t, int64_t n_slices, int64_t B,
                            double* sums, void* stream_) {
@@ -977,6 +1209,10 @@ static int loss_terms_impl(CnfModel* m, const CnfLossSpec* spec, const float* pt
   if (n_slices == 0) return CNF_OK;
   if (hipMemsetAsync(sums, 0, sizeof(double) * (size_t)n_slices, stream) != hipSuccess) return CNF_ERR_HIP;
   if (B == 0) return CNF_OK;
+  {
+    const int r = loss_terms_pwl(m, spec, pts, slice_stride, seed, first_sample, t, n_slices, B, sums, stream);
+    if (r != CNF_ERR_UNSUPPORTED) return r;
+  }
 
   LossArgs a;
   a.m = model_args(m); a.spec = *spec; a.pts = pts; a.t = t; a.sums = sums;

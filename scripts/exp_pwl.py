@@ -48,3 +48,24 @@ for rnd in range(6):
 for name, v in res.items():
   v.sort()
   print(f"{name:6s} median {v[len(v)//2]:.4f} ms  min {v[0]:.4f} ms  -> {S*B/v[len(v)//2]/1e6:.2f} G samples/s")
+
+# fused loss terms (in-kernel noise): MLP loss kernel vs the tables
+from cnf_ot_amd import applications as app, _capi
+ts = np.linspace(0, 1, S).astype(np.float32)
+specs = {"kinetic": app._spec(_capi.TERM_KINETIC, dt=0.01),
+         "kinetic_score": app._spec(_capi.TERM_KINETIC_SCORE, dt=0.01, dx=0.01, coef=0.5),
+         "potential": app._spec(_capi.TERM_POTENTIAL, subtype=2),
+         "reverse_kl": app._spec(_capi.TERM_REVERSE_KL, T=1.0, beta=4.0)}
+for tag, spec in specs.items():
+  vals = {}
+  for name, e in engines.items():
+    for _ in range(2):
+      r = e.loss_terms_seeded(spec, 9, ts, B, first_sample=0, slice_stride=B)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(4):
+      r = e.loss_terms_seeded(spec, 9, ts, B, first_sample=0, slice_stride=B)
+    e1.record(); torch.cuda.synchronize()
+    vals[name] = (e0.elapsed_time(e1) / 4, float(r.sum()) / (S * B))
+  print(f"[loss {tag}] mlp {vals['mlp'][0]:.3f} ms ({vals['mlp'][1]:.8g})   tables {vals['pwl'][0]:.3f} ms ({vals['pwl'][1]:.8g})")

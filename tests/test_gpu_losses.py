@@ -47,12 +47,15 @@ def _check(name, got, want, rtol=RTOL):
   assert rel <= rtol, (name, got, want, rel)
 
 
-@pytest.mark.parametrize("spl", [1, 2])
+@pytest.mark.parametrize("spl", [1, 2, "tables"])
 def test_single_terms_dim2(dev, spl):
+  """spl = 1 / 2: the MLP loss kernel with one / two samples per lane;
+  "tables": loss_pwl_kernel (conditioner from the piecewise-linear tables)."""
   from oracle import losses as ol
   from cnf_ot_amd import applications as app
   model, params, flow = _setup(dev)
-  model.engine(dev).set_samples_per_lane(spl)
+  model.engine(dev).set_pwl(2 if spl == "tables" else 0)
+  model.engine(dev).set_samples_per_lane(0 if spl == "tables" else spl)
   B, seed, t = 4096 + 37, 42, 0.4          # ragged batch: partial tiles
   z = _noise(model, params, seed, B)
   _check("kinetic", app.kinetic_loss_fn(model, 2, 0.01, params, t, seed, B), ol.kinetic_loss_fn(flow, 2, 0.01, t, z))
@@ -73,6 +76,7 @@ def test_single_terms_dim2(dev, spl):
       _check(f"kl[{src},c={c}]", app.kl_loss_fn(model, 2, 1.0, params, c, seed, B, source=src),
              ol.kl_loss_fn(flow, 1.0, c, z, src, comp), rtol=2e-5)
   model.engine(dev).set_samples_per_lane(0)
+  model.engine(dev).set_pwl(1)
 
 
 def test_composite_losses_reference_configs(dev):
@@ -123,13 +127,15 @@ def test_fokker_planck_dim10_and_lorenz_dim3(dev):
          ol.flow_matching_loss_fn(flow3, 3, 1.0, 0.5, "lorenz", 0.3, z3))
 
 
-def test_evaluators_fused_slices(dev):
+@pytest.mark.parametrize("pwl", [0, 2], ids=["mlp", "tables"])
+def test_evaluators_fused_slices(dev, pwl):
   """utils.calc_kinetic_energy / calc_score_kinetic_energy: many slices per
   launch, each slice its own block of the noise stream."""
   from oracle import losses as ol
   from cnf_ot_amd import utils as amd_utils
   model, params, flow = _setup(dev)
   be = model.terms_backend(params)
+  be.set_pwl(pwl)
   Bs, S = 8192, 7
   draw = lambda k: be.normal(5, Bs, first_sample=k * Bs).cpu().double().numpy()
   got = amd_utils.calc_kinetic_energy(model.apply.sample, params, 5, batch_size=Bs, t_size=S, dim=2,
@@ -169,8 +175,11 @@ def test_seeded_terms_equal_tensor_terms(dev):
     ts = np.linspace(0.1, 0.9, S).astype(np.float32)
     for spec in (app._spec(_capi.TERM_KINETIC, dt=0.01), app._spec(_capi.TERM_POTENTIAL, subtype=2),
                  app._spec(_capi.TERM_REVERSE_KL, T=1.0, beta=4.0)):
-      for spl in (1, 2):
-        be.set_samples_per_lane(spl)
+      for spl in (1, 2, "tables"):
+        if spl == "tables" and D != 2:
+          continue
+        be.set_pwl(2 if spl == "tables" else 0)
+        be.set_samples_per_lane(0 if spl == "tables" else spl)
         own = torch.cat([be.normal(9, B, first_sample=first + s * B) for s in range(S)])
         a = be.loss_terms(spec, own, ts, B, False)
         b = be.loss_terms_seeded(spec, 9, ts, B, first_sample=first, slice_stride=B)
@@ -180,3 +189,4 @@ def test_seeded_terms_equal_tensor_terms(dev):
         b = be.loss_terms_seeded(spec, 9, ts, B, first_sample=first, slice_stride=0)
         assert torch.allclose(a, b, rtol=1e-12, atol=1e-9)
     be.set_samples_per_lane(0)
+    be.set_pwl(1)
