@@ -224,6 +224,32 @@ def test_config2_piecewise_linear_tables(dev, params_kind):
   assert (y0 - y).abs().max().item() <= 1e-5 and (lp0 - lp).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("L", [1, 3, 4])
+def test_table_path_other_depths(dev, L):
+  """The table path with 1, 3 and 4 flow layers (L tables of 21 KB in LDS;
+  the layer permutation alternates), both directions, vs the oracle."""
+  import oracle
+  fcfg, ocfg = _cfg_pair(D=2, L=L)
+  rng = np.random.default_rng(20 + L)
+  params = rng.normal(0, 0.2, oracle.param_count(ocfg)).astype(np.float32).astype(np.float64)
+  S, Bs = 3, 6000
+  noise = rng.normal(size=(S * Bs, 2)).astype(np.float32)
+  ts = np.array([0.1, 0.5, 0.9])
+  c_host = np.repeat(ts, Bs)
+  eng = _engine(fcfg, params, dev)
+  eng.set_pwl(2)
+  y, lp = eng.sample_logprob(_t(noise, dev), _t(ts, dev))
+  y_ref, lp_ref = oracle.sample_logprob(ocfg, params, noise.astype(np.float64), c_host)
+  assert _err(y, y_ref).max() <= TOL_Y and _err(lp, lp_ref).max() <= TOL_LP_SAMPLE * max(1, L / 2)
+  y_in = y_ref.astype(np.float32)
+  lpd_ref = oracle.log_prob(ocfg, params, y_in.astype(np.float64), c_host)
+  elpd = _err(eng.log_prob(_t(y_in, dev), _t(ts, dev)), lpd_ref)
+  assert elpd.max() <= TOL_LP_DATA_MAX * max(1, L / 2) and np.quantile(elpd, 0.999) <= TOL_LP_DATA_P999 * max(1, L / 2)
+  eng.set_pwl(0)
+  y0, lp0 = eng.sample_logprob(_t(noise, dev), _t(ts, dev))
+  assert (y0 - y).abs().max().item() <= 2e-5 and (lp0 - lp).abs().max().item() <= 2e-5
+
+
 def test_table_path_on_two_streams(dev):
   """The conditioner tables live in a workspace per (model, stream): calls of
   one model issued on two streams, with different slice counts (one grows its
