@@ -339,7 +339,7 @@ __device__ __forceinline__ void pwl_stage(float* tbl, const float* __restrict__ 
     const int rows = n + 1 < PWL_LROWS ? n + 1 : PWL_LROWS;
     const f4* src = reinterpret_cast<const f4*>(g);
     f4* dst = reinterpret_cast<f4*>(tbl + l * PWL_LTBL);
-    for (int i = tid; i < (PWL_OFF_PIECE + rows * 2 * PWL_P) / 4; i += nthreads) dst[i] = src[i];
+    for (int i = tid; i < (PWL_OFF_PIECE + rows * PWL_ROW) / 4; i += nthreads) dst[i] = src[i];
   }
 }
 

@@ -31,18 +31,20 @@ constexpr int PWL_NREF = 304;             // per-piece reference points (289, pa
 constexpr int PWL_OFF_GRID = PWL_NBP;
 constexpr int PWL_OFF_REF = PWL_NBP + PWL_NG;
 constexpr int PWL_OFF_PIECE = PWL_NBP + PWL_NG + PWL_NREF;
-constexpr int PWL_TBL = PWL_OFF_PIECE + PWL_NPIECE * 2 * PWL_P;        // floats per (slice, layer): 10 384
+// A piece's row: 16 slopes + 16 intercepts, padded to 36 floats.  Lanes gather rows at unrelated p with
+// ds_read_b128; at a stride of 144 B consecutive rows start 4 x (9 p mod 16) banks apart, so the 64 lanes
+// spread over all LDS banks, and every chunk of a row is an immediate offset from ONE address per sample
+// (a 128-byte stride would put every lane on the same 8 banks; an XOR swizzle fixes that too but costs an
+// address computation per chunk).
+constexpr int PWL_ROW = 36;
+constexpr int PWL_TBL = PWL_OFF_PIECE + PWL_NPIECE * PWL_ROW;          // floats per (slice, layer): 11 540
 // The flow kernel stages the header arrays and the first PWL_LROWS rows in LDS (networks met in
 // practice have 30-50 pieces; 289 is the worst case); rows beyond that are read from the global
 // table.  21 KB per layer instead of 41 KB: three 512-thread workgroups per CU instead of one of 1024.
 constexpr int PWL_LROWS = 128;
-constexpr int PWL_LTBL = PWL_OFF_PIECE + PWL_LROWS * 2 * PWL_P;
+constexpr int PWL_LTBL = PWL_OFF_PIECE + PWL_LROWS * PWL_ROW;
 constexpr int PWL_N_SLOT = PWL_NBP - 1;   // the piece count n, stored (as int bits) in the last padding slot of bp[]
 
-// A piece's row holds 8 chunks of 4 floats (slopes 0..15, intercepts 0..15).  Lanes gather rows at
-// unrelated p with ds_read_b128; rows are 128 B apart, so chunk q of row p is stored at chunk
-// q ^ (p & 7): the 64 lanes then spread over all LDS banks instead of hitting the same 8.
-__host__ __device__ __forceinline__ int pwl_swz(int p, int e) { return ((((e >> 2) ^ (p & 7)) << 2) | (e & 3)); }
 
 // One block (512 threads) per (slice, layer).  Rows are written pre-scaled for the spline that
 // consumes them (cond_spline_masked): the 2K softmax logits in log2 units (x log2 e), the first slope
@@ -164,9 +166,9 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
       Tt += S * (double)uref;
       if (m == 0) T[PWL_OFF_REF + p] = uref;
       if (m < 10) { S *= LOG2E_D; Tt *= LOG2E_D; } else if (m == 10) { Tt += sp_offset; }
-      float* row = T + PWL_OFF_PIECE + p * 2 * PWL_P;
-      row[pwl_swz(p, m)] = (float)S;
-      row[pwl_swz(p, PWL_P + m)] = (float)Tt;
+      float* row = T + PWL_OFF_PIECE + p * PWL_ROW;
+      row[m] = (float)S;
+      row[PWL_P + m] = (float)Tt;
     }
     __syncthreads();
   }
@@ -184,7 +186,8 @@ __device__ __forceinline__ float fma_scalar(float a, float b, float c) {
 typedef const f4 __attribute__((address_space(3))) * lds_f4_ptr;
 
 __device__ __forceinline__ int pwl_cell(float u) {
-  const int cell = (int)floorf((u - PWL_GMIN) * PWL_GSCALE);
+  // truncation == floor for the cells that survive the clamp (negative values go to cell 0 either way)
+  const int cell = (int)fmaf(u, PWL_GSCALE, -PWL_GMIN * PWL_GSCALE);
   return cell < 0 ? 0 : (cell > PWL_NG - 1 ? PWL_NG - 1 : cell);
 }
 
@@ -192,24 +195,20 @@ __device__ __forceinline__ int pwl_cell(float u) {
 __device__ __forceinline__ void pwl_row(const float* tbl, const float* __restrict__ gtbl, int p, float u,
                                         float (&th)[PWL_P]) {
   const float du = u - tbl[PWL_OFF_REF + p];
-  const uint32_t z4 = ((uint32_t)p & 7u) << 4;
   if (p < PWL_LROWS) {
-    // byte address of chunk q of row p: row + ((q << 4) ^ ((p & 7) << 4)) -- one v_xad_u32 per chunk
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(tbl + PWL_OFF_PIECE);    // low 32 bits of a flat LDS address = LDS offset
-    const uint32_t row = lds0 + ((uint32_t)p << 7);
+    // ONE address per sample; the 8 chunks are immediate offsets of the ds_read_b128s
+    const lds_f4_ptr row = (lds_f4_ptr)(uintptr_t)((uint32_t)(uintptr_t)(tbl + PWL_OFF_PIECE) + (uint32_t)p * (PWL_ROW * 4));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f4 s = *(lds_f4_ptr)(uintptr_t)((z4 ^ (uint32_t)(q << 4)) + row);
-      const f4 t = *(lds_f4_ptr)(uintptr_t)((z4 ^ (uint32_t)((4 + q) << 4)) + row);
+      const f4 s = row[q], t = row[4 + q];
 #pragma unroll
       for (int e = 0; e < 4; ++e) th[4 * q + e] = fma_scalar(s[e], du, t[e]);
     }
   } else {
-    const char* row = reinterpret_cast<const char*>(gtbl + PWL_OFF_PIECE + p * 2 * PWL_P);
+    const f4* row = reinterpret_cast<const f4*>(gtbl + PWL_OFF_PIECE + p * PWL_ROW);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f4 s = *reinterpret_cast<const f4*>(row + (z4 ^ (uint32_t)(q << 4)));
-      const f4 t = *reinterpret_cast<const f4*>(row + (z4 ^ (uint32_t)((4 + q) << 4)));
+      const f4 s = row[q], t = row[4 + q];
 #pragma unroll
       for (int e = 0; e < 4; ++e) th[4 * q + e] = fma_scalar(s[e], du, t[e]);
     }
