@@ -181,7 +181,7 @@ def main():
 
   # dominant kernel: average launch duration from HIP events on the launch stream
   full = [(a.elapsed_time(b) * 1e-3, s) for a, b, s in events if s == S] or \
-         [(a.elapsed_time(b) * 1e-3, s) for a, b, s in events]
+         [(a.elapsed_time(b) * 1e-3, s) for a, b, s in events] or [(float("nan"), 0)]    # a rank with no step
   k_dur = sum(d for d, _ in full) / len(full)
   k_samples = full[0][1] * b_local
   achieved_tflops = FLOP_PER_SAMPLE * k_samples / k_dur / 1e12
