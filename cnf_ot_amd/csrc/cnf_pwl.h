@@ -38,9 +38,9 @@ constexpr int PWL_OFF_PIECE = PWL_NBP + PWL_NG + PWL_NREF;
 // address computation per chunk).
 constexpr int PWL_ROW = 36;
 constexpr int PWL_TBL = PWL_OFF_PIECE + PWL_NPIECE * PWL_ROW;          // floats per (slice, layer): 11 540
-// The flow kernel stages the header arrays and the first PWL_LROWS rows in LDS (networks met in
-// practice have 30-50 pieces; 289 is the worst case); rows beyond that are read from the global
-// table.  21 KB per layer instead of 41 KB: three 512-thread workgroups per CU instead of one of 1024.
+// The flow and loss kernels stage the header arrays and the first PWL_LROWS rows in LDS (networks met in
+// practice have 30-50 pieces; 289 is the worst case); rows beyond that are read from the global table.
+// 23 KB per table instead of 46 KB: the loss kernel keeps up to three table sets of L = 2 layers in LDS.
 constexpr int PWL_LROWS = 128;
 constexpr int PWL_LTBL = PWL_OFF_PIECE + PWL_LROWS * PWL_ROW;
 constexpr int PWL_N_SLOT = PWL_NBP - 1;   // the piece count n, stored (as int bits) in the last padding slot of bp[]
@@ -48,8 +48,9 @@ constexpr int PWL_N_SLOT = PWL_NBP - 1;   // the piece count n, stored (as int b
 
 // One block (512 threads) per (slice, layer).  Rows are written pre-scaled for the spline that
 // consumes them (cond_spline_masked): the 2K softmax logits in log2 units (x log2 e), the first slope
-// logit with the softplus offset added, the other K as differences to their predecessor.  Rows past the last piece are never read (the
-// search stops at the +inf padding) and are left unwritten.
+// logit with the softplus offset added, the other K as differences to their predecessor.  Rows past
+// the last piece are never read (the search stops at the +inf padding) and are left unwritten.
+// `c_offset` is added to the slice's condition (the loss kernels need t - dt/2 and t + dt/2).
 constexpr int PWL_CHUNK = 64;             // pieces per pass of the two-stage affine-map computation
 
 __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict__ weights /* prep + hdr */,
@@ -122,9 +123,11 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
   float* T = tables + (int64_t)blockIdx.x * PWL_TBL;
   for (int p = tid; p < PWL_NBP; p += blockDim.x)
     T[p] = p == PWL_N_SLOT ? __int_as_float(n) : (p < n ? (float)cand[p] : __int_as_float(0x7f800000));
-  // coarse grid: number of breakpoints <= the cell's left edge (a lower bound for the scan)
+  // coarse grid: number of breakpoints <= the cell's left edge (a lower bound for the scan).  The edge is
+  // pulled in by 1e-4: pwl_cell() computes the cell in fp32, and u a rounding error below an edge may land
+  // in the cell above it.
   for (int g = tid; g < PWL_NG; g += blockDim.x) {
-    const double x = (double)PWL_GMIN + (double)g / (double)PWL_GSCALE;
+    const double x = (double)PWL_GMIN + (double)g / (double)PWL_GSCALE - 1e-4;
     int lo_ = 0, hi_ = g == 0 ? 0 : n;          // cell 0 also serves every u below the grid: scan from piece 0
     while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (cand[mid] <= x) lo_ = mid + 1; else hi_ = mid; }
     reinterpret_cast<int*>(T + PWL_OFF_GRID)[g] = lo_;
@@ -174,7 +177,6 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
   }
 }
 
-// theta(u) from the (slice, layer) table staged in LDS
 // The compiler would pair the two samples' FMAs into v_pk_fma_f32 and pay ~40 v_mov to interleave
 // the two gathered rows; a plain v_fma_f32 per half needs none.
 __device__ __forceinline__ float fma_scalar(float a, float b, float c) {
