@@ -14,7 +14,9 @@ SRC_DIR = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcnf_ot_amd.so")
 SOURCES = ["cnf_flow.hip", "cnf_grad.hip"]
-HEADERS = ["cnf_device.h", "cnf_common.h", "cnf_backward.h", os.path.join("..", "..", "include", "cnf_ot_amd.h")]
+HEADERS = ["cnf_device.h", "cnf_common.h", "cnf_backward.h", "cnf_pwl.h",
+           os.path.join("..", "..", "include", "cnf_ot_amd.h")]
+VARIANT_PATH = os.path.join(LIB_DIR, "BUILD_VARIANT")     # "full" or "minimal": what the .so in tree contains
 ARCH = "gfx950"
 
 
@@ -25,8 +27,18 @@ def _hipcc():
   raise RuntimeError("hipcc not found (need ROCm's hipcc to build the gfx950 kernels)")
 
 
-def is_stale() -> bool:
+def _variant() -> str:
+  try:
+    with open(VARIANT_PATH) as f:
+      return f.read().strip()
+  except OSError:
+    return ""
+
+
+def is_stale(minimal: bool = False) -> bool:
   if not os.path.exists(LIB_PATH):
+    return True
+  if not minimal and _variant() != "full":     # a quick-iteration build must never pass for the full one
     return True
   t = os.path.getmtime(LIB_PATH)
   deps = [os.path.join(SRC_DIR, f) for f in SOURCES + HEADERS]
@@ -36,7 +48,7 @@ def is_stale() -> bool:
 def build(force: bool = False, minimal: bool = False, verbose: bool = False) -> str:
   """Compile every HIP source into one shared library.  `minimal` builds only
   the default (hidden_size=16, num_bins=5) kernels -- for quick iteration."""
-  if not force and not is_stale():
+  if not force and not is_stale(minimal):
     return LIB_PATH
   os.makedirs(LIB_DIR, exist_ok=True)
   cmd = [_hipcc(), "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared",
@@ -52,6 +64,8 @@ def build(force: bool = False, minimal: bool = False, verbose: bool = False) -> 
   if res.returncode != 0:
     raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
   os.replace(tmp, LIB_PATH)
+  with open(VARIANT_PATH, "w") as f:
+    f.write("minimal\n" if minimal else "full\n")
   return LIB_PATH
 
 
