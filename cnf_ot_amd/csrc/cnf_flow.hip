@@ -1023,6 +1023,8 @@ static int pwl_workspace(CnfModel* m, hipStream_t stream, int64_t n_slices, floa
   return CNF_OK;
 }
 
+static const int64_t PWL_MAX_SLICES = 2048;      // slices per build + flow kernel pair
+
 static bool pwl_config_ok(const CnfModel* m) {
   const CnfConfig& g = m->cfg;
   return m->use_pwl && m->fast_math && g.dim == 2 && g.hidden_size == cnf::PWL_H && g.num_bins == 5 &&
@@ -1056,29 +1058,36 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
   // the tables cost one small kernel per launch: worth it once every CU has a tile,
   // and only while a slice is long enough to amortise building its tables
   if (m->use_pwl == 1 && (total < m->num_cus || slice_len < 4 * PWL_TS)) return CNF_ERR_UNSUPPORTED;
+  if (pwl_min_lds > lds) lds = pwl_min_lds;
+  if (to_base ? !ensure_lds(cnf::flow_pwl_kernel<5, true, true>, lds) : !ensure_lds(cnf::flow_pwl_kernel<5, false, true>, lds))
+    return CNF_ERR_UNSUPPORTED;
+  // at most PWL_MAX_SLICES slices per kernel pair: the workspace stays bounded (2 048 x L x 46 KB) however many
+  // slices a call has
+  const int64_t chunk = n_slices < PWL_MAX_SLICES ? n_slices : PWL_MAX_SLICES;
   float* tables = nullptr;
   {
-    const int r = pwl_workspace(m, stream, n_slices, &tables);
+    const int r = pwl_workspace(m, stream, chunk, &tables);
     if (r != CNF_OK) return r;
   }
-  hipLaunchKernelGGL(cnf::pwl_build_kernel, dim3((unsigned)(n_slices * L)), dim3(512), 0, stream,
-                     (const float*)(m->prep + cnf::hdr_floats(5)), m->per_layer, c, 0.0f, L,
-                     log(exp(1.0 - (double)m->cfg.min_knot_slope) - 1.0), tables);
-  cnf::PwlArgs a;
-  a.m = model_args(m);
-  a.in = in; a.out = out; a.aux = aux; a.tables = tables;
-  a.B = B; a.slice_len = slice_len;
-  a.n_slices = (int32_t)n_slices; a.tiles_per_slice = (int32_t)tps; a.aux_mode = aux_mode;
-  if (pwl_min_lds > lds) lds = pwl_min_lds;
-  int64_t per_cu = (160 * 1024) / (int64_t)lds;
-  if (per_cu > 2048 / pwl_threads) per_cu = 2048 / pwl_threads;
-  int64_t grid = total < m->num_cus * per_cu ? total : m->num_cus * per_cu;
-  if (to_base) {
-    if (!ensure_lds(cnf::flow_pwl_kernel<5, true, true>, lds)) return CNF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, true, true>), dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
-  } else {
-    if (!ensure_lds(cnf::flow_pwl_kernel<5, false, true>, lds)) return CNF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, false, true>), dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
+  const double sp_offset = log(exp(1.0 - (double)m->cfg.min_knot_slope) - 1.0);
+  for (int64_t s0 = 0; s0 < n_slices; s0 += chunk) {
+    const int64_t ns = n_slices - s0 < chunk ? n_slices - s0 : chunk;
+    const int64_t first = s0 * slice_len;
+    hipLaunchKernelGGL(cnf::pwl_build_kernel, dim3((unsigned)(ns * L)), dim3(512), 0, stream,
+                       (const float*)(m->prep + cnf::hdr_floats(5)), m->per_layer, c + s0, 0.0f, L, sp_offset, tables);
+    cnf::PwlArgs a;
+    a.m = model_args(m);
+    a.in = in + first * 2; a.out = out ? out + first * 2 : nullptr; a.aux = aux ? aux + first : nullptr;
+    a.tables = tables;
+    a.B = (B - first) < ns * slice_len ? (B - first) : ns * slice_len;
+    a.slice_len = slice_len;
+    a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps; a.aux_mode = aux_mode;
+    const int64_t tiles = ns * tps;
+    const int64_t grid = tiles < m->num_cus ? tiles : m->num_cus;
+    if (to_base)
+      hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, true, true>), dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
+    else
+      hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, false, true>), dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
   }
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
@@ -1162,27 +1171,34 @@ static int loss_terms_pwl(CnfModel* m, const CnfLossSpec* spec, const float* pts
   const int64_t total = n_slices * tps;
   if (total > (1 << 30)) return CNF_ERR_UNSUPPORTED;
   if (m->use_pwl == 1 && (total < m->num_cus || B < 4 * ts)) return CNF_ERR_UNSUPPORTED;
+  if (!ensure_lds(cnf::loss_pwl_kernel<5, true>, lds)) return CNF_ERR_UNSUPPORTED;
+  const int64_t chunk = n_slices < PWL_MAX_SLICES ? n_slices : PWL_MAX_SLICES;
   float* tables = nullptr;
   {
-    const int r = pwl_workspace(m, stream, n_slices * n_sets, &tables);
+    const int r = pwl_workspace(m, stream, chunk * n_sets, &tables);
     if (r != CNF_OK) return r;
   }
   const double sp_offset = log(exp(1.0 - (double)m->cfg.min_knot_slope) - 1.0);
-  const int64_t set_stride = n_slices * L * (int64_t)cnf::PWL_TBL;
-  for (int s = 0; s < n_sets; ++s) {          // conditions t - dt/2, t + dt/2, t (kinetic kinds) or t
-    const float off = !kin ? 0.0f : (s == 0 ? -0.5f * spec->dt : (s == 1 ? 0.5f * spec->dt : 0.0f));
-    hipLaunchKernelGGL(cnf::pwl_build_kernel, dim3((unsigned)(n_slices * L)), dim3(512), 0, stream,
-                       (const float*)(m->prep + cnf::hdr_floats(5)), m->per_layer, t, off, L, sp_offset,
-                       tables + s * set_stride);
+  for (int64_t s0 = 0; s0 < n_slices; s0 += chunk) {
+    const int64_t ns = n_slices - s0 < chunk ? n_slices - s0 : chunk;
+    const int64_t set_stride = ns * L * (int64_t)cnf::PWL_TBL;
+    for (int s = 0; s < n_sets; ++s) {          // conditions t - dt/2, t + dt/2, t (kinetic kinds) or t
+      const float off = !kin ? 0.0f : (s == 0 ? -0.5f * spec->dt : (s == 1 ? 0.5f * spec->dt : 0.0f));
+      hipLaunchKernelGGL(cnf::pwl_build_kernel, dim3((unsigned)(ns * L)), dim3(512), 0, stream,
+                         (const float*)(m->prep + cnf::hdr_floats(5)), m->per_layer, t + s0, off, L, sp_offset,
+                         tables + s * set_stride);
+    }
+    cnf::LossPwlArgs a;
+    a.m = model_args(m); a.spec = *spec; a.t = t + s0; a.sums = sums + s0; a.tables = tables;
+    // slice s of the chunk is slice s0 + s of the call: its points / stream positions start s0 * stride later
+    a.pts = pts ? pts + s0 * slice_stride * 2 : nullptr;
+    a.B = B; a.n_slices = ns; a.pts_slice_stride = slice_stride;
+    a.seed = seed; a.first_sample = first_sample + s0 * slice_stride;
+    a.n_sets = n_sets; a.tiles_per_slice = (int32_t)tps;
+    const int64_t tiles = ns * tps;
+    const int64_t grid = tiles < m->num_cus ? tiles : m->num_cus;
+    hipLaunchKernelGGL((cnf::loss_pwl_kernel<5, true>), dim3((unsigned)grid), dim3(threads), lds, stream, a);
   }
-  cnf::LossPwlArgs a;
-  a.m = model_args(m); a.spec = *spec; a.pts = pts; a.t = t; a.sums = sums; a.tables = tables;
-  a.B = B; a.n_slices = n_slices; a.pts_slice_stride = slice_stride;
-  a.seed = seed; a.first_sample = first_sample;
-  a.n_sets = n_sets; a.tiles_per_slice = (int32_t)tps;
-  const int64_t grid = total < m->num_cus ? total : m->num_cus;
-  if (!ensure_lds(cnf::loss_pwl_kernel<5, true>, lds)) return CNF_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((cnf::loss_pwl_kernel<5, true>), dim3((unsigned)grid), dim3(threads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 

@@ -250,6 +250,30 @@ def test_table_path_other_depths(dev, L):
   assert (y0 - y).abs().max().item() <= 2e-5 and (lp0 - lp).abs().max().item() <= 2e-5
 
 
+def test_table_path_many_slices(dev):
+  """More slices than one build + flow kernel pair takes (2 048): the call is
+  processed in chunks against a bounded workspace; same numbers as the MLP
+  kernel, chunk boundaries included."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params, applications as app, _capi
+  cfg = FlowConfig(dim=2)
+  eng = FlowEngine(cfg, dev).load(Params.random(cfg, 0.2, seed=6, device=dev))
+  S, Bs = 2048 * 2 + 77, 64
+  x = eng.normal(3, S * Bs)
+  t = torch.rand(S, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+  res = {}
+  for mode in (0, 2):
+    eng.set_pwl(mode)
+    y, lp = eng.sample_logprob(x, t)
+    kin = eng.loss_terms_seeded(app._spec(_capi.TERM_KINETIC, dt=0.01), 11, t.cpu().numpy(), Bs, first_sample=5, slice_stride=Bs)
+    res[mode] = (y, lp, kin)
+  # two fp32 evaluations, each within ~5e-6 of the float64 value
+  assert (res[0][0] - res[2][0]).abs().max().item() <= 2e-5
+  assert (res[0][1] - res[2][1]).abs().max().item() <= 2e-5
+  rel = ((res[0][2] - res[2][2]).abs() / res[0][2].abs().clamp_min(1e-6)).max().item()
+  assert rel <= 1e-4, rel
+  eng.set_pwl(1)
+
+
 def test_table_path_on_two_streams(dev):
   """The conditioner tables live in a workspace per (model, stream): calls of
   one model issued on two streams, with different slice counts (one grows its
