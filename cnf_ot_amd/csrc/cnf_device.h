@@ -369,12 +369,13 @@ __device__ __forceinline__ v2f step_mask(v2f d, v2f big) {
 }
 
 // cond_spline for sample pairs fed from the piecewise-linear tables: rows hold
-// the softmax logits in log2 units, t_0 + softplus offset, and the DIFFERENCES
-// D_k = t_k - t_(k-1) of the slope logits.  The bin is selected arithmetically
-// with 0/1 masks m_k = [v > knot_k] in packed FMAs (38 packed instructions per
-// pair instead of 8 compares + 48 v_cndmask):
-//   x0 = lo + sum m_k w_(k-1)  (bitwise the running knot),   t0 = t_0 + sum m_k D_k,
-//   bw = sum (m_k - m_(k+1)) w_k  (one-hot, exact),          t1 = t_1 + sum m_k D_(k+1).
+// the softmax logits in log2 units and the slope logits with the softplus
+// offset added.  The bin is selected arithmetically with 0/1 masks m_k =
+// [v > knot_k] in packed FMAs (40 packed instructions per pair instead of 8
+// compares + 48 v_cndmask):
+//   x0 = lo + sum m_k w_(k-1)  (bitwise the running knot),
+//   bw, bh, t0, t1 = sum o_k (w_k, h_k, t_k, t_(k+1))  with the one-hot o_k = m_k - m_(k+1)
+// -- products with 0 or 1 and sums of zeros: bitwise the selected values.
 template <int K, bool INV, bool FAST>
 __device__ __forceinline__ void cond_spline_masked(const v2f (&th)[3 * K + 1], v2f v,
                                                    const SplineConsts& sc, v2f& out, v2f& ld) {
@@ -393,8 +394,8 @@ __device__ __forceinline__ void cond_spline_masked(const v2f (&th)[3 * K + 1], v
   const T big = splat<T>(1.152921504606846976e18f);       // 2^60
   T px = splat<T>(sc.lo), py = splat<T>(sc.lo);            // running knot k
   T wp = vfma(ew[0], aw, splat<T>(sc.min_bin)), hp = vfma(eh[0], ah, splat<T>(sc.min_bin));   // bin k-1
-  T x0 = px, y0 = py, t0 = th[2 * K], t1 = th[2 * K] + th[2 * K + 1];
-  T mprev = splat<T>(1.0f), bw = splat<T>(0.0f), bh = splat<T>(0.0f);
+  T x0 = px, y0 = py;
+  T mprev = splat<T>(1.0f), bw = splat<T>(0.0f), bh = splat<T>(0.0f), t0 = splat<T>(0.0f), t1 = splat<T>(0.0f);
 #pragma unroll
   for (int k = 1; k < K; ++k) {
     px += wp;
@@ -403,16 +404,18 @@ __device__ __forceinline__ void cond_spline_masked(const v2f (&th)[3 * K + 1], v
     const T o = mprev - m;                                  // one-hot of bin k-1
     bw = k == 1 ? o * wp : vfma(o, wp, bw);
     bh = k == 1 ? o * hp : vfma(o, hp, bh);
+    t0 = k == 1 ? o * th[2 * K] : vfma(o, th[2 * K + k - 1], t0);
+    t1 = k == 1 ? o * th[2 * K + 1] : vfma(o, th[2 * K + k], t1);
     x0 = vfma(m, wp, x0);
     y0 = vfma(m, hp, y0);
-    t0 = vfma(m, th[2 * K + k], t0);
-    t1 = vfma(m, th[2 * K + k + 1], t1);
     if (k == K - 1) { wp = sc.hi - px; hp = sc.hi - py; }   // last knot is exactly hi
     else { wp = vfma(ew[k], aw, splat<T>(sc.min_bin)); hp = vfma(eh[k], ah, splat<T>(sc.min_bin)); }
     mprev = m;
   }
   bw = vfma(mprev, wp, bw);
   bh = vfma(mprev, hp, bh);
+  t0 = vfma(mprev, th[3 * K - 1], t0);
+  t1 = vfma(mprev, th[3 * K], t1);
   const T d0 = knot_slope<FAST, T, true>(t0, sc), d1 = knot_slope<FAST, T, true>(t1, sc);
   const T ibw = M::rcp(bw);
   const T s = bh * ibw;

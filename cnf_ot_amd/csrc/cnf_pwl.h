@@ -11,9 +11,11 @@
 // replaces the 2 -> 16 -> 16 -> 16 MLP (544 FMAs per sample) by a search in
 // the breakpoints and 16 FMAs.  The function evaluated is the same network;
 // only the rounding differs (the table is rounded once from float64).  Each
-// piece's map is stored about a reference point INSIDE the piece, theta =
-// S (u - u_ref) + T: an intercept referred to u = 0 would cancel against S u
-// for pieces far from the origin.
+// piece's map is stored about a reference point near the samples it serves,
+// theta = S (u - u_ref) + T with u_ref the point of the piece nearest to 0
+// (clamped to the search grid): an intercept referred to u = 0 would cancel
+// against S u for pieces far from the origin, one referred to the midpoint of a
+// very wide piece would do the same for samples near its inner end.
 #pragma once
 
 #include "cnf_common.h"
@@ -47,8 +49,8 @@ constexpr int PWL_N_SLOT = PWL_NBP - 1;   // the piece count n, stored (as int b
 
 
 // One block (512 threads) per (slice, layer).  Rows are written pre-scaled for the spline that
-// consumes them (cond_spline_masked): the 2K softmax logits in log2 units (x log2 e), the first slope
-// logit with the softplus offset added, the other K as differences to their predecessor.  Rows past
+// consumes them (cond_spline_masked): the 2K softmax logits in log2 units (x log2 e), the K + 1 slope
+// logits with the softplus offset added.  Rows past
 // the last piece are never read (the search stops at the +inf padding) and are left unwritten.
 // `c_offset` is added to the slice's condition (the loss kernels need t - dt/2 and t + dt/2).
 constexpr int PWL_CHUNK = 64;             // pieces per pass of the two-stage affine-map computation
@@ -155,20 +157,22 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
     __syncthreads();
     for (int t = tid; t < np * PWL_P; t += blockDim.x) {
       const int pl = t >> 4, m = t & 15, p = base + pl;
-      // slope logits m = 11 .. 15 are stored as differences t_m - t_(m-1) (cond_spline_masked)
-      const bool diff = m > 10;
-      double S = 0.0, Tt = diff ? bo[m] - bo[m - 1] : bo[m];
+      double S = 0.0, Tt = bo[m];
       for (int k = 0; k < PWL_H; ++k) {
-        const double wo = diff ? Wo[k * PWL_P + m] - Wo[k * PWL_P + m - 1] : Wo[k * PWL_P + m];
+        const double wo = Wo[k * PWL_P + m];
         S += wo * PQ[2 * (pl * PWL_H + k)];
         Tt += wo * PQ[2 * (pl * PWL_H + k) + 1];
       }
-      // refer the map to the piece's own test point (as rounded to float)
+      // Refer the map to the point of the piece nearest to 0, kept inside the search grid: samples live
+      // there, and a piece can be thousands wide (a midpoint reference at u ~ 1000 makes S (u - u_ref) and
+      // T cancel catastrophically for u ~ 10).  The reference need not lie inside the piece -- T is the
+      // value of the piece's affine map at u_ref, not of the network.
       const double lo = p == 0 ? -INF : cand[p - 1], hi = p < n ? cand[p] : INF;
-      const float uref = (float)test_point(lo, hi);
+      const double nearest = lo > 0.0 ? lo : (hi < 0.0 ? hi : 0.0);
+      const float uref = (float)(nearest < (double)PWL_GMIN ? (double)PWL_GMIN : (nearest > -(double)PWL_GMIN ? -(double)PWL_GMIN : nearest));
       Tt += S * (double)uref;
       if (m == 0) T[PWL_OFF_REF + p] = uref;
-      if (m < 10) { S *= LOG2E_D; Tt *= LOG2E_D; } else if (m == 10) { Tt += sp_offset; }
+      if (m < 10) { S *= LOG2E_D; Tt *= LOG2E_D; } else { Tt += sp_offset; }
       float* row = T + PWL_OFF_PIECE + p * PWL_ROW;
       row[m] = (float)S;
       row[PWL_P + m] = (float)Tt;

@@ -159,13 +159,14 @@ def _zigzag_params(rng, n):
   return params.astype(np.float32).astype(np.float64)
 
 
-@pytest.mark.parametrize("params_kind", ["zeros", "random", "first_only", "zigzag"])
+@pytest.mark.parametrize("params_kind", ["zeros", "random", "first_only", "zigzag", "wide_pieces"])
 def test_config2_piecewise_linear_tables(dev, params_kind):
   """The dim-2 fast path (cnf_pwl.h): conditioner read from exact piecewise-
   linear tables built per (slice, layer).  Same bars as the MLP kernels, on
   slices of ragged (even) length with a partial last slice; `zeros` and
   `first_only` (all conditioner weights zero) are the degenerate one-piece
-  tables, `zigzag` the near-worst-case piece count."""
+  tables, `zigzag` the near-worst-case piece count, `wide_pieces` breakpoints
+  far outside the data."""
   import oracle
   fcfg, ocfg = _cfg_pair(D=2)
   rng = np.random.default_rng(11)
@@ -177,6 +178,13 @@ def test_config2_piecewise_linear_tables(dev, params_kind):
     params[:16] = rng.normal(0, 0.5, 16).astype(np.float32)
   elif params_kind == "zigzag":
     params = _zigzag_params(rng, n)
+  elif params_kind == "wide_pieces":
+    # half of the first-layer units barely depend on u: their breakpoints sit at |u| ~ 1e3, so the pieces
+    # that serve the samples are thousands wide (the affine maps must be referred to a point near the samples)
+    params = rng.normal(0, 0.2, n)
+    for l in range(2):
+      params[16 + 592 * l + 16: 16 + 592 * l + 24] *= 1e-3
+    params = params.astype(np.float32).astype(np.float64)
   S, Bs = 7, 9998                      # 7 slices of 9 998 = 4 tiles of 2 048 + a partial one
   B = S * Bs - 4000                    # the last slice is short
   noise = rng.normal(size=(S * Bs, 2)).astype(np.float32)
@@ -269,8 +277,10 @@ def test_table_path_many_slices(dev):
   # two fp32 evaluations, each within ~5e-6 of the float64 value
   assert (res[0][0] - res[2][0]).abs().max().item() <= 2e-5
   assert (res[0][1] - res[2][1]).abs().max().item() <= 2e-5
+  # a slice sums only 64 finite-difference velocities (fp32 noise ~1e-3 each): loose per slice, tight in total
   rel = ((res[0][2] - res[2][2]).abs() / res[0][2].abs().clamp_min(1e-6)).max().item()
-  assert rel <= 1e-4, rel
+  tot = abs(float(res[0][2].sum() - res[2][2].sum())) / float(res[0][2].sum())
+  assert rel <= 5e-3 and tot <= 1e-5, (rel, tot)
   eng.set_pwl(1)
 
 
