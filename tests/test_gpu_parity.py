@@ -258,6 +258,56 @@ def test_table_path_other_depths(dev, L):
   assert (y0 - y).abs().max().item() <= 2e-5 and (lp0 - lp).abs().max().item() <= 2e-5
 
 
+def test_table_path_randomised_against_mlp_kernel_and_oracle(dev):
+  """A small fixed-seed cut of scripts/soak_pwl.py: parameter sets of scale
+  0.05 .. 1.5 with sparse / tied / far-breakpoint weights, inputs of spread
+  1 .. 8.  Ill-conditioned sets have large fp32 errors in BOTH kernels, so the
+  criterion is relative: the table path is never further from the float64 oracle
+  than 3x the MLP kernel (+ the fp32 floor), for samples, log_prob and the
+  data->base log_prob."""
+  import oracle
+  fcfg, ocfg = _cfg_pair(D=2)
+  rng = np.random.default_rng(123)
+  for case in range(18):
+    scale = float(rng.choice([0.05, 0.1, 0.2, 0.3, 0.5, 0.8, 1.5]))
+    w = rng.normal(0, scale, 1200)
+    kind = case % 6
+    if kind == 1:
+      w[rng.random(1200) < 0.5] = 0.0
+    elif kind == 2:
+      for l in range(2):
+        blk = w[16 + 592 * l: 16 + 592 * (l + 1)]
+        blk[16:24] = blk[24:32]; blk[0:8] = blk[8:16]; blk[32:40] = blk[40:48]
+    elif kind == 3:
+      for l in range(2):
+        w[16 + 592 * l + 16: 16 + 592 * l + 24] *= 1e-3
+    elif kind == 4:
+      for l in range(2):
+        w[16 + 592 * l + 32: 16 + 592 * l + 48] *= 40.0
+    params = w.astype(np.float32)
+    S, Bs = 3, 3000
+    ts = rng.uniform(-0.5, 1.5, S).astype(np.float32)
+    noise = (rng.normal(size=(S * Bs, 2)) * float(rng.choice([1.0, 3.0, 8.0]))).astype(np.float32)
+    c64 = np.repeat(ts.astype(np.float64), Bs)
+    y64, lp64 = oracle.sample_logprob(ocfg, params.astype(np.float64), noise.astype(np.float64), c64)
+    y_in = np.clip(y64, -1e6, 1e6).astype(np.float32)
+    lpd64 = oracle.log_prob(ocfg, params.astype(np.float64), y_in.astype(np.float64), c64)
+    eng = _engine(fcfg, params, dev)
+    err = {}
+    for mode in (0, 2):
+      eng.set_pwl(mode)
+      y, lp = eng.sample_logprob(_t(noise, dev), _t(ts, dev))
+      lpd = eng.log_prob(_t(y_in, dev), _t(ts, dev))
+      err[mode] = [np.abs(y.cpu().double().numpy() - y64).max(1), np.abs(lp.cpu().double().numpy() - lp64),
+                   np.abs(lpd.cpu().double().numpy() - lpd64)]
+    for q, (e_mlp, e_tab) in enumerate(zip(err[0], err[2])):
+      fin = np.isfinite(e_mlp) & np.isfinite(e_tab)
+      assert (np.isfinite(e_mlp) == np.isfinite(e_tab)).all(), (case, q)
+      e_mlp, e_tab = e_mlp[fin], e_tab[fin]
+      assert np.median(e_tab) <= 3 * np.median(e_mlp) + 1e-6, (case, kind, scale, q)
+      assert np.quantile(e_tab, 0.999) <= 3 * np.quantile(e_mlp, 0.999) + 5e-5, (case, kind, scale, q)
+
+
 def test_table_path_many_slices(dev):
   """More slices than one build + flow kernel pair takes (2 048): the call is
   processed in chunks against a bounded workspace; same numbers as the MLP
