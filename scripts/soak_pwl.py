@@ -63,13 +63,14 @@ for case in range(n_cases):
   q = lambda e: (np.median(e), np.quantile(e, 0.999), e.max())
   fin_d = np.isfinite(lpd64) & np.isfinite(lpd[0]) & np.isfinite(lpd[2])
   ed_mlp = np.abs(lpd[0] - lpd64)[fin_d]; ed_pwl = np.abs(lpd[2] - lpd64)[fin_d]
-  term_rel = max(float(np.nanmax(np.abs(a - b) / np.maximum(np.abs(a), 1e-3))) for a, b in zip(terms[0], terms[2]))
+  term_rels = [float(np.nanmax(np.abs(a - b) / np.maximum(np.abs(a), 1e-3))) for a, b in zip(terms[0], terms[2])]
+  term_rel = max(term_rels)
   ok_extra = (np.quantile(ed_pwl, 0.999) <= 3 * np.quantile(ed_mlp, 0.999) + 5e-5 and np.median(ed_pwl) <= 3 * np.median(ed_mlp) + 1e-6)
   ok = ok_extra and (np.quantile(e_pwl, 0.999) <= 3 * np.quantile(e_mlp, 0.999) + 2e-5 and np.median(e_pwl) <= 3 * np.median(e_mlp) + 1e-6
         and np.quantile(ey_pwl, 0.999) <= 3 * np.quantile(ey_mlp, 0.999) + 2e-5 and nan_mismatch == 0)
   bad += 0 if ok else 1
   print(f"case {case:3d} kind {kind} scale {scale:4.2f} spread {spread:3.0f}: logp err mlp med/p999/max {q(e_mlp)[0]:.1e}/{q(e_mlp)[1]:.1e}/{q(e_mlp)[2]:.1e}"
         f"  tables {q(e_pwl)[0]:.1e}/{q(e_pwl)[1]:.1e}/{q(e_pwl)[2]:.1e}  y p999 {np.quantile(ey_mlp, .999):.1e}/{np.quantile(ey_pwl, .999):.1e}"
-        f"  log_prob(data->base) p999 {np.quantile(ed_mlp, .999):.1e}/{np.quantile(ed_pwl, .999):.1e}  loss terms rel diff {term_rel:.1e}"
+        f"  log_prob(data->base) p999 {np.quantile(ed_mlp, .999):.1e}/{np.quantile(ed_pwl, .999):.1e}  loss terms rel diff {term_rel:.1e} (kinetic {term_rels[0]:.1e} score {term_rels[1]:.1e} rkl {term_rels[2]:.1e}; sums {terms[0][0][0]:.3g} {terms[0][1][0]:.3g} {terms[0][2][0]:.3g})"
         f"  nonfinite mismatch {nan_mismatch} {'OK' if ok else 'WORSE'}")
 print("cases:", n_cases, "table path worse than the MLP kernel in:", bad)
