@@ -308,6 +308,39 @@ def test_table_path_randomised_against_mlp_kernel_and_oracle(dev):
       assert np.quantile(e_tab, 0.999) <= 3 * np.quantile(e_mlp, 0.999) + 5e-5, (case, kind, scale, q)
 
 
+def test_entry_points_are_graph_capturable(dev):
+  """include/cnf_ot_amd.h: compute entry points only enqueue work on the given
+  stream.  Capture a sampling call of each kernel family into a HIP graph
+  (torch.cuda.CUDAGraph captures the current stream), replay it on new inputs,
+  compare with eager calls.  The table path needs its one warm-up call first
+  (its workspace is allocated by the first call on a stream)."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  cfg = FlowConfig(dim=2)
+  eng = FlowEngine(cfg, dev).load(Params.random(cfg, 0.2, seed=8, device=dev))
+  S, Bs = 4, 4096
+  x = eng.normal(1, S * Bs)
+  t = torch.linspace(0.2, 0.8, S, device=dev)
+  y = torch.empty(S * Bs, 2, device=dev); lp = torch.empty(S * Bs, device=dev)
+  for mode in (0, 2):
+    eng.set_pwl(mode)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+      eng.sample_logprob(x, t, out=y, logp_out=lp)            # warm-up on the capturing stream
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+      eng.sample_logprob(x, t, out=y, logp_out=lp)
+    x.copy_(eng.normal(2 + mode, S * Bs))                      # new inputs in the captured buffers
+    t.copy_(torch.linspace(0.3, 0.9, S, device=dev))
+    graph.replay()
+    torch.cuda.synchronize()
+    y_g, lp_g = y.clone(), lp.clone()
+    y_e, lp_e = eng.sample_logprob(x, t)
+    assert torch.equal(y_g, y_e) and torch.equal(lp_g, lp_e), mode
+  eng.set_pwl(1)
+
+
 def test_table_path_many_slices(dev):
   """More slices than one build + flow kernel pair takes (2 048): the call is
   processed in chunks against a bounded workspace; same numbers as the MLP
