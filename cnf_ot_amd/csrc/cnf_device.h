@@ -758,4 +758,23 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// Counter block `blk` of the base-noise stream of `seed` -> its four standard
+// normals (Philox4x32-10, two Box-Muller pairs from 24-bit uniforms).  Element
+// e of the stream is z[e & 3] of block e >> 2: cnf_fill_normal, the in-kernel
+// draws of the loss kernels and the oracle all go through this definition.
+__device__ __forceinline__ void philox_normals4(uint64_t seed, uint64_t blk, float (&z)[4]) {
+  uint32_t u[4];
+  philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), u);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float u1 = (float)((u[2 * p] >> 8) + 1u) * (1.0f / 16777216.0f);
+    const float u2 = (float)(u[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincospif(2.0f * u2, &sn, &cs);
+    z[2 * p] = rad * cs;
+    z[2 * p + 1] = rad * sn;
+  }
+}
+
 }  // namespace cnf

@@ -453,22 +453,14 @@ __device__ __forceinline__ void tile_noise(uint64_t seed, uint64_t first_element
   const int n_blk = (int)(((first_element + (uint64_t)(TS * D) - 1) >> 2) - blk0) + 1;
   for (int q = threadIdx.x; q < n_blk; q += TILE) {
     const uint64_t blk = blk0 + (uint64_t)q;
-    uint32_t u[4];
-    philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), u);
+    float z[4];
+    philox_normals4(seed, blk, z);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const float u1 = (float)((u[2 * p] >> 8) + 1u) * (1.0f / 16777216.0f);
-      const float u2 = (float)(u[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
-      const float rad = sqrtf(-2.0f * logf(u1));
-      float sn, cs;
-      sincospif(2.0f * u2, &sn, &cs);
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int64_t e = (int64_t)((blk << 2) + 2 * p + r) - (int64_t)first_element;
-        if (e >= 0 && e < TS * D) {
-          const int s = magic ? (int)__umulhi((uint32_t)e, magic) : (int)e, d = (int)e - s * D;
-          U[d * TS + s] = e < n_el ? (r == 0 ? rad * cs : rad * sn) : 0.0f;
-        }
+    for (int r = 0; r < 4; ++r) {
+      const int64_t e = (int64_t)((blk << 2) + r) - (int64_t)first_element;
+      if (e >= 0 && e < TS * D) {
+        const int s = magic ? (int)__umulhi((uint32_t)e, magic) : (int)e, d = (int)e - s * D;
+        U[d * TS + s] = e < n_el ? z[r] : 0.0f;
       }
     }
   }
@@ -625,16 +617,9 @@ struct LossPwlArgs {
 };
 
 __device__ __forceinline__ float normal_at(uint64_t seed, uint64_t e) {     // element e of the cnf_fill_normal stream
-  const uint64_t blk = e >> 2;
-  uint32_t u[4];
-  philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), u);
-  const int p = (int)(e & 3) >> 1;
-  const float u1 = (float)((u[2 * p] >> 8) + 1u) * (1.0f / 16777216.0f);
-  const float u2 = (float)(u[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
-  const float rad = sqrtf(-2.0f * logf(u1));
-  float sn, cs;
-  sincospif(2.0f * u2, &sn, &cs);
-  return (e & 1) == 0 ? rad * cs : rad * sn;
+  float z[4];
+  philox_normals4(seed, e >> 2, z);
+  return z[e & 3];
 }
 
 template <int K, bool FAST>
@@ -685,18 +670,10 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void loss_pwl_kernel(const LossPwl
     } else {
       const uint64_t e0 = (uint64_t)(a.first_sample + g) * 2u;
       if ((e0 & 3) == 0) {                                  // one Philox block holds the pair
-        uint32_t u[4];
-        philox4x32((uint32_t)(e0 >> 2), (uint32_t)(e0 >> 34), 0u, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), u);
+        float z[4];
+        philox_normals4(a.seed, e0 >> 2, z);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const float u1 = (float)((u[2 * p] >> 8) + 1u) * (1.0f / 16777216.0f);
-          const float u2 = (float)(u[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
-          const float rad = sqrtf(-2.0f * logf(u1));
-          float sn, cs;
-          sincospif(2.0f * u2, &sn, &cs);
-          x[2 * p] = rad * cs;
-          x[2 * p + 1] = rad * sn;
-        }
+        for (int q = 0; q < 4; ++q) x[q] = z[q];
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) x[q] = normal_at(a.seed, e0 + q);
@@ -778,19 +755,8 @@ __global__ void fill_normal_kernel(uint64_t seed, uint64_t first_element, int64_
   const uint64_t last_blk = (first_element + (uint64_t)n - 1) >> 2;
   for (uint64_t blk = first_blk + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; blk <= last_blk;
        blk += (uint64_t)gridDim.x * blockDim.x) {
-    uint32_t u[4];
-    philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), u);
     float z[4];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const float u1 = (float)((u[2 * p] >> 8) + 1u) * (1.0f / 16777216.0f);
-      const float u2 = (float)(u[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
-      const float rad = sqrtf(-2.0f * logf(u1));
-      float sn, cs;
-      sincospif(2.0f * u2, &sn, &cs);
-      z[2 * p] = rad * cs;
-      z[2 * p + 1] = rad * sn;
-    }
+    philox_normals4(seed, blk, z);
     const uint64_t e0 = blk << 2;
     if (e0 >= first_element && e0 + 3 < first_element + (uint64_t)n && (((e0 - first_element) & 3) == 0) &&
         ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
