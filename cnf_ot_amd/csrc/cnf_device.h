@@ -173,9 +173,6 @@ template <> struct Math<false> {
   static __device__ __forceinline__ double div(double a, double b) { return a / b; }
   static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
   static __device__ __forceinline__ v2f exp(v2f x) { return v2f{expf(x.x), expf(x.y)}; }
-  static __device__ __forceinline__ float exp2(float x) { return exp2f(x); }
-  static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
-  static __device__ __forceinline__ v2f exp2(v2f x) { return v2f{exp2f(x.x), exp2f(x.y)}; }
   static __device__ __forceinline__ v2f log(v2f x) { return v2f{logf(x.x), logf(x.y)}; }
   static __device__ __forceinline__ v2f rcp(v2f x) { return v2f{1.0f / x.x, 1.0f / x.y}; }
   static __device__ __forceinline__ v2f div(v2f a, v2f b) { return v2f{a.x / b.x, a.y / b.y}; }
@@ -354,10 +351,7 @@ __device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab,
 }
 
 // ---------------------------------------------------------------------------
-// Spline whose 3K+1 parameters were just produced by the conditioner, one set
-// per sample, in registers.  The bin is selected with a compare/select chain
-// over the running knot (registers cannot be indexed per lane); only the two
-// slopes of the selected bin are normalised (2 softplus instead of K+1).
+// The same spline for sample pairs fed from the conditioner tables (cnf_pwl.h).
 // ---------------------------------------------------------------------------
 // 0/1 mask of (d > 0) for a sample pair: clamp(d * 2^60) -- one v_pk_mul_f32
 // with the clamp modifier (differences below 2^-60 count as ties, i.e. the
@@ -434,10 +428,13 @@ __device__ __forceinline__ void cond_spline_masked(const v2f (&th)[3 * K + 1], v
   }
 }
 
-// PRE: `th` comes from the piecewise-linear tables (cnf_pwl.h), whose rows hold
-// the softmax logits in log2 units and the slope logits with the softplus
-// offset already added.
-template <int K, bool INV, bool FAST, class T, bool PRE = false>
+// ---------------------------------------------------------------------------
+// Spline whose 3K+1 parameters were just produced by the conditioner, one set
+// per sample, in registers.  The bin is selected with a compare/select chain
+// over the running knot (registers cannot be indexed per lane); only the two
+// slopes of the selected bin are normalised (2 softplus instead of K+1).
+// ---------------------------------------------------------------------------
+template <int K, bool INV, bool FAST, class T>
 __device__ __forceinline__ void cond_spline(const T (&th)[3 * K + 1], T v,
                                             const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld) {
   using M = Math<FAST>;
@@ -447,8 +444,8 @@ __device__ __forceinline__ void cond_spline(const T (&th)[3 * K + 1], T v,
   T ew[K], eh[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    ew[k] = PRE ? M::exp2(th[k] - mw) : M::exp(th[k] - mw);
-    eh[k] = PRE ? M::exp2(th[K + k] - mh) : M::exp(th[K + k] - mh);
+    ew[k] = M::exp(th[k] - mw);
+    eh[k] = M::exp(th[K + k] - mh);
   }
   T sw = ew[0], sh = eh[0];
 #pragma unroll
@@ -468,7 +465,7 @@ __device__ __forceinline__ void cond_spline(const T (&th)[3 * K + 1], T v,
     bw = vsel(ge, wk, bw); bh = vsel(ge, hk, bh);
     t0 = vsel(ge, th[2 * K + k], t0); t1 = vsel(ge, th[2 * K + k + 1], t1);
   }
-  const T d0 = knot_slope<FAST, T, PRE>(t0, sc), d1 = knot_slope<FAST, T, PRE>(t1, sc);
+  const T d0 = knot_slope<FAST, T>(t0, sc), d1 = knot_slope<FAST, T>(t1, sc);
   const T ibw = M::rcp(bw);
   const T s = bh * ibw;
   const T st = d1 + d0 - s * 2.0f;
