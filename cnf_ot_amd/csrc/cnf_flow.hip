@@ -891,7 +891,7 @@ extern "C" int cnf_model_set_fast_math(CnfModel* m, int on) {
   return CNF_OK;
 }
 
-/* Internal knob: 1 = MFMA conditioner where available (default), 0 = VALU. */
+/* Internal knob: 1 = MFMA conditioner where available, 0 = packed-VALU conditioner (default). */
 extern "C" int cnf_model_set_mfma(CnfModel* m, int on) {
   if (!m) return CNF_ERR_INVALID;
   m->use_mfma = on ? 1 : 0;

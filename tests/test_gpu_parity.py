@@ -73,8 +73,8 @@ GOLDEN = {
 @pytest.mark.parametrize("variant", ["mfma2", "mfma1", "packed2", "fast1", "ocml1", "pwl"])
 @pytest.mark.parametrize("name", sorted(GOLDEN))
 def test_golden_vectors(golden_dir, dev, name, variant):
-  """Every kernel variant: MFMA conditioner with two / one samples per lane
-  (the default for the reference's 16-wide network), packed-VALU conditioner,
+  """Every kernel variant: MFMA conditioner with two / one samples per lane,
+  packed-VALU conditioner with two samples per lane (the MLP kernels' default),
   one sample per lane, ocml expf/logf + IEEE division instead of the hardware
   transcendentals, and the piecewise-linear conditioner tables (dim 2 with a
   uniform condition; every other case must fall through to the MLP kernel)."""
