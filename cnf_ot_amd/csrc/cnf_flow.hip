@@ -1023,7 +1023,8 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
   if (total > (1 << 30)) return CNF_ERR_UNSUPPORTED;
   // the tables cost one small kernel per launch: worth it once every CU has a tile,
   // and only while a slice is long enough to amortise building its tables
-  if (m->use_pwl == 1 && (total < m->num_cus || slice_len < 4 * PWL_TS)) return CNF_ERR_UNSUPPORTED;
+  // (crossover with the MLP kernel: B / 26 G/s = 20 us of table building + B / 62 G/s  ->  B ~ 0.9 M samples)
+  if (m->use_pwl == 1 && (total < 2 * (int64_t)m->num_cus || slice_len < 4 * PWL_TS)) return CNF_ERR_UNSUPPORTED;
   if (pwl_min_lds > lds) lds = pwl_min_lds;
   if (to_base ? !ensure_lds(cnf::flow_pwl_kernel<5, true, true>, lds) : !ensure_lds(cnf::flow_pwl_kernel<5, false, true>, lds))
     return CNF_ERR_UNSUPPORTED;
@@ -1136,7 +1137,7 @@ static int loss_terms_pwl(CnfModel* m, const CnfLossSpec* spec, const float* pts
   const int64_t tps = (B + ts - 1) / ts;
   const int64_t total = n_slices * tps;
   if (total > (1 << 30)) return CNF_ERR_UNSUPPORTED;
-  if (m->use_pwl == 1 && (total < m->num_cus || B < 4 * ts)) return CNF_ERR_UNSUPPORTED;
+  if (m->use_pwl == 1 && (total < 2 * (int64_t)m->num_cus || B < 4 * ts)) return CNF_ERR_UNSUPPORTED;
   if (!ensure_lds(cnf::loss_pwl_kernel<5, true>, lds)) return CNF_ERR_UNSUPPORTED;
   const int64_t chunk = n_slices < PWL_MAX_SLICES ? n_slices : PWL_MAX_SLICES;
   float* tables = nullptr;
