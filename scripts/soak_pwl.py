@@ -9,28 +9,30 @@ sys.path.insert(0, ".")
 import oracle
 from cnf_ot_amd import FlowConfig, FlowEngine, Params, applications as app, _capi
 dev = torch.device("cuda", 0)
-cfg = FlowConfig(dim=2)
-ocfg = oracle.OracleConfig(D=2)
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 2            # flow layers
+cfg = FlowConfig(dim=2, num_layers=L)
+ocfg = oracle.OracleConfig(D=2, L=L)
+NP = cfg.param_count()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 worst = []
 bad = 0
 for case in range(n_cases):
   scale = float(rng.choice([0.05, 0.1, 0.2, 0.3, 0.5, 0.8, 1.5]))
-  w = rng.normal(0, scale, 1200)
+  w = rng.normal(0, scale, NP)
   kind = case % 6
   if kind == 1:                      # sparse weights: many exact zeros (a_j = 0, P = 0 branches)
-    w[rng.random(1200) < 0.5] = 0.0
+    w[rng.random(NP) < 0.5] = 0.0
   elif kind == 2:                    # duplicated first-layer units: tied breakpoints
-    for l in range(2):
+    for l in range(L):
       blk = w[16 + 592 * l: 16 + 592 * (l + 1)]
       blk[16:24] = blk[24:32]; blk[0:8] = blk[8:16]; blk[32:40] = blk[40:48]
   elif kind == 3:                    # spline parameters small (near-identity), conditioner large
     w[:16] *= 0.01
-    for l in range(2):
+    for l in range(L):
       w[16 + 592 * l + 320: 16 + 592 * (l + 1)] *= 0.05
   elif kind == 4:                    # huge first-layer biases: breakpoints far outside the grid
-    for l in range(2):
+    for l in range(L):
       w[16 + 592 * l + 32: 16 + 592 * l + 48] *= 40.0
   params = w.astype(np.float32)
   S, Bs = 4, 4000
