@@ -220,7 +220,7 @@ def main():
               "per sample: 2-16-16-16 MLP conditioner + splines).  The kernel reads the same conditioner from exact "
               "piecewise-linear tables and executes ~464 flop per sample, so that figure is no longer a bound "
               "(alu_reference_formulation.frac can exceed 1); the bound left is HBM.  What limits the kernel is "
-              "VALU issue, more than a third of it quarter-rate transcendentals (DESIGN.md 5.1d).",
+              "VALU issue: 797 instructions per 128-sample wave-tile (DESIGN.md 5.1d).",
     },
   }
   pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
