@@ -44,6 +44,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define S_MAX3(i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
 #define S_MED3(i) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b));
 #define S_CND(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));
+#define S_CND64(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(b) : "s20", "s21");
+#define S_CMP(i) asm volatile("v_cmp_ge_f32_e64 s[22:23], %0, %1\n v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c) : "s22", "s23");
+#define S_ADD(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+#define S_CMPCND(i) asm volatile("v_cmp_ge_f32_e64 s[22:23], %0, %1\n v_cndmask_b32_e64 %0, %0, %1, s[22:23]" : "+v"(a[i]) : "v"(b) : "s22", "s23");
 #define P_FMA(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
 #define P_MUL(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
 #define P_ADD(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
@@ -58,6 +62,21 @@ PROBE_SCALAR(k_sqrt, S_SQRT)
 PROBE_SCALAR(k_max3, S_MAX3)
 PROBE_SCALAR(k_med3, S_MED3)
 PROBE_SCALAR(k_cnd, S_CND)
+PROBE_SCALAR(k_add, S_ADD)
+PROBE_SCALAR(k_cmp_add, S_CMP)
+PROBE_SCALAR(k_cmp_cnd, S_CMPCND)
+__global__ void k_cnd64(float* out, int iters) {
+  float a[8];
+  for (int i = 0; i < 8; ++i) a[i] = 1.0f + 1e-3f * (threadIdx.x + i);
+  const float b = 1.0000001f;
+  asm volatile("s_mov_b32 s20, 0x55555555\n s_mov_b32 s21, 0x55555555" ::: "s20", "s21");
+  for (int it = 0; it < iters; ++it) {
+    CHAIN8(S_CND64)
+  }
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i) s += a[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 PROBE_PACKED(k_pk_fma, P_FMA)
 PROBE_PACKED(k_pk_mul, P_MUL)
 PROBE_PACKED(k_pk_add, P_ADD)
@@ -88,7 +107,9 @@ int main() {
   hipMalloc(&out, sizeof(float) * (size_t)num_cus * 1024);
   const int iters = 200000;
   struct { const char* name; kern_t k; } ks[] = {
-    {"v_fma_f32", k_fma}, {"v_mul_f32", k_mul}, {"v_max3_f32", k_max3}, {"v_med3_f32", k_med3}, {"v_cndmask_b32", k_cnd},
+    {"v_fma_f32", k_fma}, {"v_mul_f32", k_mul}, {"v_max3_f32", k_max3}, {"v_med3_f32", k_med3}, {"v_cndmask_b32 (vcc)", k_cnd},
+    {"v_cndmask_b32_e64 (sgpr mask)", k_cnd64}, {"v_add_f32", k_add}, {"v_cmp_ge_f32_e64 + v_add_f32", k_cmp_add},
+    {"v_cmp_ge_f32_e64 + v_cndmask_e64", k_cmp_cnd},
     {"v_pk_fma_f32", k_pk_fma}, {"v_pk_mul_f32", k_pk_mul}, {"v_pk_add_f32", k_pk_add}, {"v_pk_mul_f32 clamp", k_pk_mul_clamp},
     {"v_exp_f32", k_exp}, {"v_log_f32", k_log}, {"v_rcp_f32", k_rcp}, {"v_sqrt_f32", k_sqrt},
   };
@@ -99,7 +120,7 @@ int main() {
       const double t = run(e.k, w, iters, out, num_cus);
       const double cyc = t * clock_hz / ((double)iters * 8 * w);
       if (e.k == k_fma) ref = cyc;
-      printf("  %d wave(s)/SIMD  %-20s %6.2f cycles  (%.2f x v_fma_f32)\n", w, e.name, cyc, cyc / ref);
+      printf("  %d wave(s)/SIMD  %-34s %6.2f cycles  (%.2f x v_fma_f32)\n", w, e.name, cyc, cyc / ref);
     }
   }
   hipFree(out);
