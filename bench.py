@@ -3,19 +3,29 @@
 
 metric : MC samples/sec through flow fwd + log|det J| (sample_and_log_prob,
          the reference's conditional.py:353-402) at dim=2, batch=65536.
-step   : one pass of the hot path over one batch of 65 536 synthetic base-noise
-         samples (config 2 of BASELINE.json: OT free, dim=2) with its own
-         condition t; inputs resident in HBM before the timed region; outputs
-         y[65536,2] and log_prob[65536] written to HBM for every step.
-launch : steps are issued as fused multi-slice launches (`--slices-per-launch`
-         steps per launch, each slice with its own c) -- the shape of the
-         reference's evaluator cnf_ot/utils.py:311-340 (10 000 slices x 65 536);
-         `per_call` in the JSON line is the same work issued one launch per step.
-N GPUs : one process per GPU (torch.distributed, backend nccl = RCCL); every
-         step's batch is sample-sharded in contiguous blocks of 65536/N
-         (SURVEY.md 8e); no data-path collective; total work fixed => "strong".
+step   : ONE evaluator-shaped pass of the hot path: `--slices` (default 10 000)
+         time-slices x 65 536 base-noise samples, every slice with its own
+         condition t, through sample_and_log_prob -- the shape of the
+         reference's evaluator cnf_ot/utils.py:311-340 (10 000 slices x 65 536,
+         which the reference issues as 20 000 jitted calls; here ONE
+         cnf_sample_logprob call per rank).  Inputs are resident in HBM before
+         the timed region; y[.,2] and log_prob[.] are written for every sample.
+         Warm-up steps are identical calls (same shape, same kernels, table
+         workspace reserved before the first of them).
+N GPUs : one process per GPU (torch.distributed, backend nccl = RCCL); the
+         slices of every step are sharded over the ranks in contiguous blocks
+         (samples x slices are independent; sampling has no
+         reduction, so there is no data-path collective); total work per step
+         is fixed => "strong".
+extras : (rank 0, N=1) per-kernel HIP-event times of the same calls (roofline),
+         the single-batch call pattern (`per_call`), the dim-10 kernel against
+         its ALU roofline, the loss / value_and_grad steps of BASELINE configs
+         3-5, and the CPU baseline (the oracle, timed on a bounded sample).
+--workload cfg3|cfg4|cfg5 : times `update()` (value_and_grad + Adam, with the
+         ONE all-reduce of partial sums + gradient when sharded) instead of the
+         headline metric; own metric string.
 
-  python bench.py --gpus 1 --steps 16384 --warmup 1024
+  python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -37,45 +47,87 @@ DIM = 2
 BATCH = 65536
 # algorithmic work per sample per flow pass, fp32, default net
 FLOP_PER_SAMPLE = 2176 + 400          # conditioner MLP + splines (the reference's formulation)
+FLOP_PER_SAMPLE_D10 = 21888 + 2400
 # what the dim-2 table path executes: the conditioner is read from exact piecewise-linear tables,
 # 16 FMAs per layer instead of the 544-FMA MLP
 EXECUTED_FLOP_PER_SAMPLE = 2 * 32 + 400
 BYTES_PER_SAMPLE = 4 * (2 * DIM + 1)  # x in, y out, log_prob out (c is per slice)
 PEAK_FP32_TFLOPS = 157.3              # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 PEAK_HBM_GBS = 8000.0
+KERNEL_NAMES = {
+  "tables": "cnf::flow_pwl_kernel<5,false,true> (conditioner from piecewise-linear tables built by "
+            "cnf::pwl_build_kernel; packed fp32 VALU flow, 2 samples/lane)",
+  "mlp2": "cnf::flow_kernel<16,5,false,true,v2f> (conditioner MLP in packed fp32 VALU, 2 samples/lane)",
+  "mlp1": "cnf::flow_kernel<16,5,false,true,float> (conditioner MLP, 1 sample/lane)",
+  "mfma": "cnf::flow_kernel<16,5,false,true,.,MFMA> (conditioner on v_mfma_f32_16x16x4_f32)",
+}
 
 
 def parse_args():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=65536)
-  ap.add_argument("--warmup", type=int, default=4096)
-  ap.add_argument("--slices-per-launch", type=int, default=256)
+  ap.add_argument("--steps", type=int, default=20)
+  ap.add_argument("--warmup", type=int, default=5)
+  ap.add_argument("--slices", type=int, default=10000,
+                  help="time-slices of 65 536 samples per step (the evaluator of utils.py:311-340 has 10 000)")
   ap.add_argument("--param-scale", type=float, default=0.2)
-  ap.add_argument("--shard", choices=("slices", "samples"), default="slices",
-                  help="multi-GPU partition of the samples x time-slices grid (see main())")
+  ap.add_argument("--workload", choices=("sample", "cfg3", "cfg4", "cfg5"), default="sample")
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--cpu-seconds", type=float, default=12.0)
-  ap.add_argument("--no-per-call", action="store_true")
+  ap.add_argument("--cpu-seconds", type=float, default=10.0)
+  ap.add_argument("--no-extras", action="store_true", help="skip per_call / dim-10 / config 3-5 sections")
   ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' + "
                   "--share-device rehearses the multi-rank path on a one-GPU box")
   ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
-  ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline "
-                  "(0: min(16, affinity): a one-GPU box's CPU share)")
+  ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0: the fastest of "
+                  "{affinity, cgroup quota, 64, 32, 16}, found by a short calibration)")
   return ap.parse_args()
+
+
+def _cgroup_cpus():
+  try:
+    with open("/sys/fs/cgroup/cpu.max") as f:
+      q, p = f.read().split()
+      if q != "max":
+        return max(1, int(int(q) / int(p)))
+  except (OSError, ValueError):
+    pass
+  try:
+    with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+      q = int(f.read())
+    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+      p = int(f.read())
+    if q > 0:
+      return max(1, q // p)
+  except (OSError, ValueError):
+    pass
+  return None
 
 
 def cpu_baseline(params64, seconds, threads=0):
   """The oracle (float64 C restatement, OpenMP over the host cores) timed on a
-  bounded sample of the same workload.  A reported baseline, not the target."""
+  bounded sample of the same workload.  A reported baseline, not the target.
+  Thread count: BASELINE.md asks for all host cores of the box; a one-GPU box
+  exposes the whole host in its affinity mask but schedules a share of it, so
+  the candidates {affinity, cgroup quota, 64, 32, 16} are timed briefly and the
+  fastest is used (and reported as `cores`)."""
   import oracle
   ocfg = oracle.OracleConfig(D=DIM)
   oracle.build_library()
-  if threads <= 0:
-    threads = min(16, len(os.sched_getaffinity(0)))
-  oracle.set_num_threads(threads)
   rng = np.random.default_rng(0)
   noise = rng.normal(size=(BATCH, DIM))
+  affinity = len(os.sched_getaffinity(0))
+  tried = {}
+  if threads <= 0:
+    cands = sorted({c for c in (affinity, _cgroup_cpus(), 64, 32, 16) if c and c <= affinity}, reverse=True)
+    for c in cands:
+      oracle.set_num_threads(c)
+      oracle.sample_logprob(ocfg, params64, noise, [0.5])
+      t0 = time.perf_counter()
+      for i in range(3):
+        oracle.sample_logprob(ocfg, params64, noise, [0.25 * i])
+      tried[c] = 3 * BATCH / (time.perf_counter() - t0)
+    threads = max(tried, key=tried.get)
+  oracle.set_num_threads(threads)
   oracle.sample_logprob(ocfg, params64, noise, [0.5])          # warm-up
   t0 = time.perf_counter()
   n = 0
@@ -87,9 +139,143 @@ def cpu_baseline(params64, seconds, threads=0):
       break
   return {
     "value": n * BATCH / dt, "unit": "samples/s", "cores": oracle.num_threads(),
-    "kind": "port",
+    "kind": "port", "affinity_cores": affinity,
+    "threads_tried": {str(k): v for k, v in tried.items()},
     "sample": f"{n} batches of {BATCH} (float64 C oracle, OpenMP, {dt:.1f} s)",
   }
+
+
+def timeit(fn, min_seconds=0.5, min_calls=3):
+  """median seconds per call over >= min_calls calls and >= min_seconds of wall time."""
+  fn(); torch.cuda.synchronize()
+  ts, t_all = [], time.perf_counter()
+  while len(ts) < min_calls or time.perf_counter() - t_all < min_seconds:
+    t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    if len(ts) >= 2000:
+      break
+  return float(np.median(ts)), len(ts)
+
+
+def per_call_section(eng, model, params, noise1, t_slices, y1, lp1, dev):
+  """The reference's literal call pattern: one call per 65 536-sample batch."""
+  n_calls, S = 200, t_slices.numel()
+  out = {}
+
+  def loop(call):
+    for _ in range(20):
+      call(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_calls):
+      call(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n_calls
+
+  dt = loop(lambda i: eng.sample_logprob(noise1, t_slices[i % S:i % S + 1], out=y1, logp_out=lp1))
+  out["engine_eager"] = {"ms_per_call": dt * 1e3, "value": BATCH / dt, "kernel": eng.last_path(),
+                         "note": "FlowEngine.sample_logprob, preallocated outputs, one launch per batch"}
+  cond_b1 = [t_slices[i:i + 1].expand(BATCH).reshape(BATCH, 1).contiguous() for i in range(min(S, 8))]
+  dt = loop(lambda i: model.apply.sample_and_log_prob(params, cond=cond_b1[i % len(cond_b1)], noise=noise1))
+  out["model_apply_eager"] = {"ms_per_call": dt * 1e3, "value": BATCH / dt, "kernel": eng.last_path(),
+                              "note": "model.apply.sample_and_log_prob(params, cond=[B,1]) -- the reference's literal "
+                                      "form (applications.py:153-158), outputs allocated per call"}
+  try:       # the same launch-bound loop captured once into a HIP graph and replayed (entry points only enqueue)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+      eng.reserve(1)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+      for i in range(n_calls):
+        eng.sample_logprob(noise1, t_slices[i % S:i % S + 1], out=y1, logp_out=lp1)
+    graph.replay(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+      graph.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10 / n_calls
+    out["hip_graph"] = {"ms_per_call": dt * 1e3, "value": BATCH / dt,
+                        "note": f"{n_calls} calls captured in one graph, replayed"}
+  except Exception as exc:      # reported, never fatal for the metric
+    out["hip_graph"] = {"error": repr(exc)[:200]}
+  return out
+
+
+def dim10_section(dev):
+  """sample_and_log_prob at dim 10 against ITS roofline: fp32 ALU, 24.3 kflop per sample."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  cfg = FlowConfig(dim=10)
+  eng = FlowEngine(cfg, dev).load(Params.random(cfg, 0.12, seed=42, device=dev))
+  out = {}
+  for name, n in (("shard_32768", 32768), ("large_2M", 1 << 21)):
+    z = eng.normal(42, n)
+    c = torch.tensor([0.5], device=dev)
+    y, lp = torch.empty_like(z), torch.empty(n, device=dev)
+    eng.set_profiling(True)
+    sec, calls = timeit(lambda: eng.sample_logprob(z, c, out=y, logp_out=lp), 0.3)
+    f_ms, _, launches, smp = eng.read_profile()
+    eng.set_profiling(False)
+    k = f_ms * 1e-3 / max(launches, 1)
+    tf = FLOP_PER_SAMPLE_D10 * n / k / 1e12
+    out[name] = {"samples": n, "kernel_ms": k * 1e3, "call_ms": sec * 1e3, "samples_per_s": n / k,
+                 "kernel": eng.last_path(),
+                 "roofline": {"bound": "alu_fp32", "flop_per_sample": FLOP_PER_SAMPLE_D10, "achieved": tf,
+                              "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS}}
+  return out
+
+
+def _config_steps(dev, which, world=1):
+  """(name, update-step closure, flow passes per step, description) of BASELINE configs 3-5 (per-rank shard
+  of the global batch when torch.distributed is initialised: applications._Ctx shards by samples)."""
+  from functools import partial
+  from cnf_ot_amd import FlowConfig, FlowModel, Params, applications as app, solvers
+  if which == "cfg3":
+    cfg = FlowConfig(dim=2); B, tb = 131072, 32
+    model = FlowModel(cfg); params = Params.random(cfg, 0.2, seed=42, device=dev)
+    f = partial(app.rwpo_loss_fn, model, 2, 1.0, 1.0, 0.01, 0.01, tb, "quadratic", 1.0)
+    passes = 2 * B + tb * (B // 32) * 7
+    desc = "configs[2]: RWPO quadratic T=1 beta=1 dim=2 batch=131072, t_batch_size=32"
+  elif which == "cfg4":
+    cfg = FlowConfig(dim=10); B, tb = 262144, 32
+    model = FlowModel(cfg); params = Params.random(cfg, 0.12, seed=42, device=dev)
+    f = partial(app.fp_loss_fn, model, 10, 1.0, 1.0, 0.5, 0.01, 0.01, tb, "ou")
+    passes = B + tb * (B // 32) * 23
+    desc = "configs[3]: Fokker-Planck OU a=1 sigma=.5 dim=10 batch=262144, t_batch_size=32"
+  else:
+    cfg = FlowConfig(dim=2); B, tb = 32 << 20, 32     # kinetic + obstacle terms use batch // 32 = 2^20 per slice
+    model = FlowModel(cfg); params = Params.random(cfg, 0.2, seed=42, device=dev)
+    f = partial(app.ot_loss_fn, model, 2, 1, 0.01, tb, "obstacle", source="gaussian")
+    passes = 2 * B + tb * (B // 32) * 3
+    desc = "configs[4]: OT obstacle dim=2, 2^20 samples x 32 time-slices (kinetic + obstacle), density fit on 2^25"
+  opt = solvers.Adam(1e-3); state = opt.init(params)
+  upd = solvers.make_update(f, opt, B)
+  k = [0]
+
+  def step():
+    k[0] += 1
+    return upd(params, 1000 + k[0], 5000.0, state)[0]
+
+  return step, f, params, B, passes, desc
+
+
+def configs_section(dev):
+  out = {}
+  from cnf_ot_amd import applications as app
+  for which in ("cfg3", "cfg4", "cfg5"):
+    try:
+      step, f, params, B, passes, desc = _config_steps(dev, which)
+      # cfg4 / cfg5 here: ONE GPU's 1/8 share of the global batch (the config is an 8-GPU one)
+      share = 8 if which in ("cfg4", "cfg5") else 1
+      Bl = B // share
+      l_sec, _ = timeit(lambda: f(params, 42, 5000.0, Bl), 0.3)
+      vg = app.value_and_grad(f)
+      g_sec, _ = timeit(lambda: vg(params, 42, 5000.0, Bl), 0.3)
+      out[which] = {"workload": desc, "batch_on_this_gpu": Bl, "flow_passes": passes // share,
+                    "loss_ms": l_sec * 1e3, "value_and_grad_ms": g_sec * 1e3,
+                    "flow_passes_per_s_loss": passes / share / l_sec}
+    except Exception as exc:
+      out[which] = {"error": repr(exc)[:300]}
+  return out
 
 
 def main():
@@ -112,162 +298,175 @@ def main():
     else:
       dist.init_process_group(args.backend)
 
-  from cnf_ot_amd import FlowConfig, FlowEngine, Params
-
-  # A launch fuses many steps (batches of 65 536 samples, each with its own condition t).  The
-  # samples x time-slices grid of a launch is sharded over the ranks by whole slices: a global launch
-  # covers S * world steps and every rank processes S of them (the per-rank launch has the same shape
-  # at every N; nothing is exchanged -- sampling has no reduction).  --shard samples splits every
-  # batch instead (what the loss functions of cnf_ot_amd.applications do, where slices can be few).
-  if args.shard == "samples":
-    if BATCH % world != 0 or (BATCH // world) % 256 != 0:
-      raise SystemExit(f"batch {BATCH} does not shard into 256-sample tiles over {world} GPUs")
-    b_local, n_share, my = BATCH // world, 1, 0
-  else:
-    b_local, n_share, my = BATCH, world, rank
-  S = max(1, min(args.slices_per_launch, -(-args.steps // n_share)))
-
-  cfg = FlowConfig(dim=DIM)
-  params = Params.random(cfg, args.param_scale, seed=42, device=dev)
-  eng = FlowEngine(cfg, dev).load(params)
-
-  # synthetic inputs, resident in HBM: S distinct slices per rank; global slice g = my * S + s of a
-  # launch is samples [g*BATCH, +BATCH) of the seed-42 Philox stream (this rank's part of it)
-  noise = torch.empty(S, b_local, DIM, device=dev)
-  first = 0 if args.shard == "slices" else rank * b_local
-  for s in range(S):
-    noise[s] = eng.normal(42, b_local, first_sample=(my * S + s) * BATCH + first)
-  t_slices = torch.linspace(0.0, 1.0, S * n_share, device=dev)[my * S:(my + 1) * S].contiguous()
-  y = torch.empty(S * b_local, DIM, device=dev)
-  lp = torch.empty(S * b_local, device=dev)
-  noise_flat = noise.view(S * b_local, DIM)
-
-  def run(n_steps, events=None):
-    # n_steps global steps; a global launch takes up to S * n_share of them, this rank its share
-    done = 0
-    while done < n_steps:
-      g = min(S * n_share, n_steps - done)
-      s = g // n_share + (1 if my < g % n_share else 0)
-      done += g
-      if s == 0:
-        continue
-      if events is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-      eng.sample_logprob(noise_flat[:s * b_local], t_slices[:s], out=y[:s * b_local], logp_out=lp[:s * b_local])
-      if events is not None:
-        e1.record()
-        events.append((e0, e1, s))
-
   def barrier():
     torch.cuda.synchronize()
     if dist is not None:
       dist.barrier()
     torch.cuda.synchronize()
 
-  run(max(args.warmup, 1) if args.warmup > 0 else 0)
-  barrier()
-  events = []
+  def max_over_ranks(x):
+    if dist is None:
+      return x
+    t = torch.tensor([x], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+  if args.workload != "sample":
+    return workload_main(args, dev, dist, world, rank, barrier, max_over_ranks)
+
+  from cnf_ot_amd import FlowConfig, FlowEngine, FlowModel, Params
+  from cnf_ot_amd.distributed import Shard, shard_range
+
+  # this rank's contiguous block of the step's slices
+  s_first, S = shard_range(args.slices, Shard(rank, world))
+  cfg = FlowConfig(dim=DIM)
+  params = Params.random(cfg, args.param_scale, seed=42, device=dev)
+  model = FlowModel(cfg)
+  eng = model.engine(dev).load(params)
+  eng.reserve(S)                      # table workspace: allocated here, never inside a compute call
+
+  # synthetic inputs, resident in HBM: global slice g is samples [g*BATCH, +BATCH) of the seed-42 Philox stream
+  noise = eng.normal(42, S * BATCH, first_sample=s_first * BATCH)
+  t_slices = torch.linspace(0.0, 1.0, args.slices, device=dev)[s_first:s_first + S].contiguous()
+  y = torch.empty(S * BATCH, DIM, device=dev)
+  lp = torch.empty(S * BATCH, device=dev)
+
+  def step():
+    if S > 0:
+      eng.sample_logprob(noise, t_slices, out=y, logp_out=lp)
+
+  torch.cuda.synchronize()
   t0 = time.perf_counter()
-  run(args.steps, events)
+  step()
+  torch.cuda.synchronize()
+  cold_ms = (time.perf_counter() - t0) * 1e3       # first call: code-object load, LDS attribute; reported, not timed
+  for _ in range(max(args.warmup - 1, 0)):
+    step()
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step()
   torch.cuda.synchronize()
   elapsed = time.perf_counter() - t0
   if dist is not None:
     dist.barrier()
-    t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+  elapsed = max_over_ranks(elapsed)
+  path = eng.last_path()
   assert torch.isfinite(lp).all(), "non-finite log_prob in the bench output"
 
-  # dominant kernel: average launch duration from HIP events on the launch stream
-  full = [(a.elapsed_time(b) * 1e-3, s) for a, b, s in events if s == S] or \
-         [(a.elapsed_time(b) * 1e-3, s) for a, b, s in events] or [(float("nan"), 0)]    # a rank with no step
-  k_dur = sum(d for d, _ in full) / len(full)
-  k_samples = full[0][1] * b_local
-  achieved_tflops = FLOP_PER_SAMPLE * k_samples / k_dur / 1e12
-  executed_tflops = EXECUTED_FLOP_PER_SAMPLE * k_samples / k_dur / 1e12
-  achieved_gbs = BYTES_PER_SAMPLE * k_samples / k_dur / 1e9
+  # per-kernel durations of the SAME calls: HIP events recorded by the library on the launch stream around
+  # each kernel (cnf_model_set_profiling), over min(steps, 8) further steps -- outside the timed region, so
+  # the headline number carries no event overhead
+  eng.set_profiling(True)
+  for _ in range(min(args.steps, 8)):
+    step()
+  flow_ms, build_ms, launches, prof_samples = eng.read_profile()
+  eng.set_profiling(False)
+  k_dur = flow_ms * 1e-3 / max(launches, 1)                   # average launch duration of the dominant kernel
+  k_samples = prof_samples / max(launches, 1)
+  b_dur = build_ms * 1e-3 / max(launches, 1)
+  achieved_gbs = BYTES_PER_SAMPLE * k_samples / k_dur / 1e9 if launches else float("nan")
+  exec_flop = EXECUTED_FLOP_PER_SAMPLE if path == "tables" else FLOP_PER_SAMPLE
+  executed_tflops = exec_flop * k_samples / k_dur / 1e12 if launches else float("nan")
+  achieved_tflops = FLOP_PER_SAMPLE * k_samples / k_dur / 1e12 if launches else float("nan")
 
-  value = args.steps * BATCH / elapsed
+  total_samples = args.steps * args.slices * BATCH
+  value = total_samples / elapsed
   line = {
     "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world,
     "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
     "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
     "dtype": "f32", "data": "synthetic",
     "config": {
-      "workload": "configs[1]: OT free dim=2, batch=65536, sample_and_log_prob (RQS fwd + log|detJ|), "
-                  "L=2 H=16 M=2 K=5, params N(0,%.2f^2) seed 42" % args.param_scale,
-      "batch": BATCH, "dim": DIM, "batch_per_gpu": b_local,
-      "slices_per_launch": S, "launches": len(events),
-      "parallelism": (f"slice-shard x{world} (each rank {S} whole batches per launch)" if args.shard == "slices"
-                      else f"sample-shard x{world}"),
+      "workload": "configs[1]: OT free dim=2, batch=65536, sample_and_log_prob (RQS fwd + log|detJ|), L=2 H=16 M=2 "
+                  "K=5, params N(0,%.2f^2) seed 42; ONE STEP = one evaluator-shaped pass of %d time-slices x 65536 "
+                  "samples (cnf_ot/utils.py:311-340), each slice its own condition t, one cnf_sample_logprob call "
+                  "per rank" % (args.param_scale, args.slices),
+      "batch": BATCH, "dim": DIM, "slices_per_step": args.slices, "samples_per_step": args.slices * BATCH,
+      "slices_per_step_this_rank": S, "timed_region_s": elapsed,
+      "parallelism": f"slice-shard x{world} (contiguous blocks of the step's slices; no collective)",
     },
+    "cold_first_call_ms": cold_ms,
     "roofline": {
       # HBM: SURVEY.md 8(d)'s algorithmic bytes (20 B per sample: x in, y out, log_prob out) -- the one bound a
       # reformulation cannot move.  The ALU views are beside it.
       "bound": "hbm", "achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
       "frac": achieved_gbs / PEAK_HBM_GBS, "traffic": None,
-      "kernel": "cnf::pwl_build_kernel + cnf::flow_pwl_kernel<5,false,true> (one cnf_sample_logprob call: "
-                "piecewise-linear conditioner tables + packed fp32 VALU flow, 2 samples/lane)",
-      "launch_ms": k_dur * 1e3,
+      "kernel": KERNEL_NAMES.get(path, path), "path": path,
+      "launch_ms": k_dur * 1e3, "launches_timed": launches,
       "samples_per_launch": k_samples, "bytes_per_sample": BYTES_PER_SAMPLE,
-      "alu_executed": {"flop_per_sample": EXECUTED_FLOP_PER_SAMPLE, "achieved": executed_tflops,
+      "table_build_ms_per_launch": b_dur * 1e3,
+      "timing": "HIP events recorded by the library on the launch stream around each kernel launch "
+                "(cnf_model_set_profiling), same calls as the timed region, run right after it",
+      "alu_executed": {"flop_per_sample": exec_flop, "achieved": executed_tflops,
                        "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": executed_tflops / PEAK_FP32_TFLOPS},
       "alu_reference_formulation": {"flop_per_sample": FLOP_PER_SAMPLE, "achieved": achieved_tflops,
                                     "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                                     "frac": achieved_tflops / PEAK_FP32_TFLOPS},
       "note": "SURVEY.md 8(d) derived an fp32-ALU bound of 60 G samples/s from the reference formulation (2576 flop "
-              "per sample: 2-16-16-16 MLP conditioner + splines).  The kernel reads the same conditioner from exact "
-              "piecewise-linear tables and executes ~464 flop per sample, so that figure is no longer a bound "
+              "per sample: 2-16-16-16 MLP conditioner + splines).  The table path reads the same conditioner from "
+              "exact piecewise-linear tables and executes ~464 flop per sample, so that figure is no longer a bound "
               "(alu_reference_formulation.frac can exceed 1); the bound left is HBM.  What limits the kernel is "
-              "VALU issue: 797 instructions per 128-sample wave-tile (DESIGN.md 5.1d).",
+              "VALU issue (DESIGN.md 5.1d).",
     },
   }
   pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-  if os.path.exists(pmc):
+  if os.path.exists(pmc) and launches:
     with open(pmc) as f:
       rec = json.load(f)
     if rec.get("samples_per_launch"):
+      # PMC counters (separate rocprofv3 --pmc passes of this command) are per launch of the profiled run;
+      # rescaled by samples only when the profiled launch had another size (the kernel streams: bytes ~ samples)
       line["roofline"]["traffic"] = rec["bytes_per_launch"] * k_samples / rec["samples_per_launch"]
       line["roofline"]["traffic_source"] = rec.get("source", "profiles/hbm_traffic.json")
+      line["roofline"]["traffic_samples_per_launch"] = rec["samples_per_launch"]
 
-  if not args.no_per_call and rank == 0 and world == 1:
-    n_calls = 200
-    for _ in range(20):
-      eng.sample_logprob(noise_flat[:b_local], t_slices[:1], out=y[:b_local], logp_out=lp[:b_local])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(n_calls):
-      eng.sample_logprob(noise_flat[:b_local], t_slices[i % S:i % S + 1], out=y[:b_local], logp_out=lp[:b_local])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    line["per_call"] = {"ms_per_step": dt / n_calls * 1e3, "value": n_calls * BATCH / dt,
-                        "note": "one launch per 65536-sample step, eager (MLP kernel: a single batch "
-                                "does not amortise building the tables)"}
-    # the same launch-bound loop captured once into a HIP graph and replayed (entry points only enqueue)
-    try:
-      side = torch.cuda.Stream(device=dev)
-      side.wait_stream(torch.cuda.current_stream(dev))
-      graph = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(graph, stream=side):
-        for i in range(n_calls):
-          eng.sample_logprob(noise_flat[:b_local], t_slices[i % S:i % S + 1], out=y[:b_local], logp_out=lp[:b_local])
-      graph.replay(); torch.cuda.synchronize()
-      t0 = time.perf_counter()
-      for _ in range(5):
-        graph.replay()
-      torch.cuda.synchronize()
-      dt = (time.perf_counter() - t0) / 5
-      line["per_call"]["hip_graph"] = {"ms_per_step": dt / n_calls * 1e3, "value": n_calls * BATCH / dt,
-                                       "note": f"{n_calls} calls captured in one graph, replayed"}
-    except Exception as exc:      # reported, never fatal for the metric
-      line["per_call"]["hip_graph"] = {"error": repr(exc)[:200]}
+  if rank == 0 and world == 1 and not args.no_extras:
+    nb = min(S, 64)
+    line["per_call"] = per_call_section(eng, model, params, noise[:BATCH], t_slices[:nb], y[:BATCH], lp[:BATCH], dev)
+    del noise, y, lp
+    torch.cuda.empty_cache()
+    line["dim10"] = dim10_section(dev)
+    line["configs"] = configs_section(dev)
 
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     line["cpu_baseline"] = cpu_baseline(params.flat.cpu().double().numpy(), args.cpu_seconds, args.cpu_threads)
   elif rank == 0:
     line["cpu_baseline"] = None
 
+  if rank == 0:
+    print(json.dumps(line), flush=True)
+  if dist is not None:
+    dist.destroy_process_group()
+
+
+def workload_main(args, dev, dist, world, rank, barrier, max_over_ranks):
+  """--workload cfg3|cfg4|cfg5: a step = update() = value_and_grad + Adam of that BASELINE config, global batch
+  sample-sharded over the ranks, ONE sum all-reduce of [partial sums, gradient] per step (RCCL through
+  torch.distributed; applications._Ctx.reduce)."""
+  step, f, params, B, passes, desc = _config_steps(dev, args.workload, world)
+  for _ in range(max(args.warmup, 1)):
+    loss = step()
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    loss = step()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  if dist is not None:
+    dist.barrier()
+  elapsed = max_over_ranks(elapsed)
+  assert torch.isfinite(torch.as_tensor(loss)).all(), "non-finite loss"
+  line = {
+    "metric": "flow passes/sec through update() (value_and_grad + Adam) of " + args.workload,
+    "value": passes * args.steps / elapsed, "unit": "flow passes/s", "n_gpus": world, "steps": args.steps,
+    "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+    "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+    "config": {"workload": desc, "global_batch": B, "flow_passes_per_step": passes,
+               "parallelism": f"sample-shard x{world}; one sum all-reduce of partial sums + gradient "
+                              f"({params.flat.numel()} floats) per step"},
+    "loss": float(loss),
+  }
   if rank == 0:
     print(json.dumps(line), flush=True)
   if dist is not None:

@@ -51,6 +51,11 @@ SYMBOLS = {
   "cnf_model_create": (ctypes.c_int, [_CFG, ctypes.POINTER(_P)]),
   "cnf_model_destroy": (None, [_P]),
   "cnf_model_set_params": (ctypes.c_int, [_P, _P, _P]),
+  "cnf_model_reserve": (ctypes.c_int, [_P, _P, _I64]),
+  "cnf_model_reserved": (_I64, [_P, _P]),
+  "cnf_model_table_bytes": (_I64, [_P]),
+  "cnf_model_last_path": (ctypes.c_int, [_P]),
+  "cnf_model_set_precise": (ctypes.c_int, [_P, ctypes.c_int]),
   "cnf_forward_logdet": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
   "cnf_inverse_logdet": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
   "cnf_log_prob": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _P]),
@@ -80,7 +85,11 @@ _INTERNAL = {
   "cnf_model_set_samples_per_lane": (ctypes.c_int, [_P, ctypes.c_int]),
   "cnf_model_set_mfma": (ctypes.c_int, [_P, ctypes.c_int]),
   "cnf_model_set_pwl": (ctypes.c_int, [_P, ctypes.c_int]),
+  "cnf_model_set_profiling": (ctypes.c_int, [_P, ctypes.c_int]),
+  "cnf_model_read_profile": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
 }
+PATH_NAMES = {0: "none", 1: "mlp1", 2: "mlp2", 3: "mfma", 4: "tables", 5: "loss_mlp", 6: "loss_tables", 7: "f64"}
 
 _lib = None
 

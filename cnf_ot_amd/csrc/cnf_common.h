@@ -3,6 +3,7 @@
 #pragma once
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "cnf_device.h"
 #include "../../include/cnf_ot_amd.h"
@@ -21,6 +22,7 @@ struct ModelArgs {
   SplineConsts sc;
   SplineConstsT<double> scd;   // the same constants in float64 (exact-mode kernels)
   const double* tabd;          // float64 copy of the `first` table (inside prep)
+  const double* e2tab;         // 2^(-i/32), i = 0 .. 1024 (inside prep): the precise position path
 };
 
 template <class R> __device__ __forceinline__ const SplineConstsT<R>& sc_of(const ModelArgs& a);
@@ -62,6 +64,8 @@ struct CnfModel {
   cnf::SplineConsts sc;
   cnf::SplineConstsT<double> scd;
   int64_t tabd_off;       // offset (in floats, 8-byte aligned) of the float64 table inside prep
+  int64_t e2_off;         // offset (in floats, 8-byte aligned) of the 2^(-i/32) table inside prep
+  int precise;            // 1 (default): data -> base entry points run the precise position path
   float* prep;            // device
   int64_t n_params;
   int64_t per_layer;
@@ -77,11 +81,31 @@ struct CnfModel {
   float* grad_slabs;      // per-wave gradient slabs (cnf_grad_enable), or null
   int64_t grad_max_blocks;
   int use_pwl;            // 1: piecewise-linear conditioner tables at dim 2 (cnf_pwl.h)
-  // table workspaces [slices][L][PWL_TBL], one per stream that has run the table path (so calls on
-  // different streams never share one), grown on demand
-  struct PwlWorkspace { float* tables; int64_t slices; };
+  // table workspaces [sets][L][PWL_TBL], one per stream (calls on different streams never share one).
+  // Allocated ONLY by cnf_model_reserve; the compute entry points look theirs up and never allocate.
+  struct PwlWorkspace { float* tables; int64_t sets; };
   std::mutex pwl_mu;
   std::unordered_map<void*, PwlWorkspace> pwl_ws;
+  // cnf_model_set_params records `prep_event` after its kernel; a compute call on another stream waits for it
+  hipEvent_t prep_event;
+  void* prep_stream;
+  int last_path;          // CnfPath of the most recent compute call (cnf_model_last_path)
+  // cnf_model_set_profiling: HIP events around the kernels of the flow entry points
+  struct ProfRec { hipEvent_t e0, e1, e2; int64_t samples; int path; };
+  int profiling;
+  std::vector<ProfRec> prof;
+};
+
+// which kernels a compute call ran (cnf_model_last_path)
+enum CnfPath {
+  CNF_PATH_NONE = 0,
+  CNF_PATH_MLP1 = 1,        // flow_kernel, one sample per lane
+  CNF_PATH_MLP2 = 2,        // flow_kernel, packed fp32, two samples per lane
+  CNF_PATH_MFMA = 3,        // flow_kernel with the MFMA conditioner
+  CNF_PATH_TABLES = 4,      // pwl_build_kernel + flow_pwl_kernel
+  CNF_PATH_LOSS_MLP = 5,    // loss_kernel
+  CNF_PATH_LOSS_TABLES = 6, // pwl_build_kernel + loss_pwl_kernel
+  CNF_PATH_F64 = 7,         // float64 instantiation
 };
 
 #ifdef CNF_MINIMAL_CONFIGS   /* faster builds while iterating on the kernels */
@@ -93,11 +117,29 @@ struct CnfModel {
 
 // Dynamic LDS above the 64 KB default needs an explicit opt-in per kernel; the
 // CU has 160 KB.  Returns false if the request cannot be met.
+// The attribute is set once per (kernel, device) for the whole CU (a launch then needs no runtime call but
+// the launch itself).
 template <class K>
 static inline bool ensure_lds(K kernel, size_t bytes) {
   if (bytes > 160 * 1024) return false;
   if (bytes <= 64 * 1024) return true;
-  return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+  static std::mutex mu;
+  static std::unordered_map<int, bool> done;       // one map per kernel instantiation, keyed by device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find(dev);
+  if (it != done.end()) return it->second;
+  const bool ok = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+  done[dev] = ok;
+  return ok;
+}
+
+// Orders a compute call after the last cnf_model_set_params when that ran on a different stream.
+static inline int wait_for_params(CnfModel* m, hipStream_t stream) {
+  if (m->prep_event && m->prep_stream != (void*)stream)
+    if (hipStreamWaitEvent(stream, m->prep_event, 0) != hipSuccess) return CNF_ERR_HIP;
+  return CNF_OK;
 }
 
 static inline cnf::ModelArgs model_args(const CnfModel* m) {
@@ -107,5 +149,6 @@ static inline cnf::ModelArgs model_args(const CnfModel* m) {
   a.D = m->cfg.dim; a.L = m->cfg.num_layers; a.M = m->cfg.mlp_num_layers;
   a.sc = m->sc; a.scd = m->scd;
   a.tabd = reinterpret_cast<const double*>(m->prep + m->tabd_off);
+  a.e2tab = reinterpret_cast<const double*>(m->prep + m->e2_off);
   return a;
 }

@@ -64,6 +64,8 @@ enum TabField {
   F_XK,      // x knots [K+1]
   F_YK,      // y knots [K+1]
   F_TAIL,    // d_lo, d_hi, log d_lo, log d_hi, 1/d_lo, 1/d_hi
+  F_X0L,     // float64 knot - (float)knot of F_X0 / F_Y0: the precise position path carries the bin's
+  F_Y0L,     // corner as a float pair
   F_COUNT
 };
 enum { T_DLO = 0, T_DHI, T_LOG_DLO, T_LOG_DHI, T_INV_DLO, T_INV_DHI };
@@ -324,17 +326,36 @@ template <> struct BinRow<v2f> {
   template <int K> __device__ __forceinline__ v2f get(int f) const { return v2f{px[tab_off(f, K)], py[tab_off(f, K)]}; }
 };
 
-template <int K, bool INV, bool FAST, class T>
+// PRECISE (forward direction only): the bin corner (x0, y0) is a float pair hi + lo rounded from the float64
+// table, the offset inside the bin is (v - x0_hi) - x0_lo and the result y0_hi + (y0_lo + increment); `out_lo`
+// receives what rounding `out` to fp32 dropped (for the base term -x^2/2 of log_prob).
+template <int K, bool INV, bool FAST, class T, bool PRECISE = false>
 __device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab, T v,
-                                             const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld) {
+                                             const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld,
+                                             T& out_lo) {
   typedef typename Lanes<T>::real R;
   const R* pos = tab + tab_off(INV ? F_YK : F_XK, K);
   const typename Lanes<T>::index k = bin_of<K>(pos, v);
   const BinRow<T> row(tab, k);
-  rqs_bin_eval<INV, FAST, T>(v, row.template get<K>(F_X0), row.template get<K>(F_Y0), row.template get<K>(F_BW),
-                             row.template get<K>(F_BH), row.template get<K>(F_IBW),
-                             row.template get<K>(F_S), row.template get<K>(F_ST), row.template get<K>(F_D0),
-                             row.template get<K>(F_D1), row.template get<K>(F_L2S), out, ld);
+  if constexpr (PRECISE && !INV) {
+    using M = Math<FAST>;
+    const T x0 = row.template get<K>(F_X0), y0 = row.template get<K>(F_Y0), bh = row.template get<K>(F_BH);
+    const T s = row.template get<K>(F_S), st = row.template get<K>(F_ST);
+    const T d0 = row.template get<K>(F_D0), d1 = row.template get<K>(F_D1);
+    const T z = clip01(((v - x0) - row.template get<K>(F_X0L)) * row.template get<K>(F_IBW));
+    const T sq_z = z * z, z1mz = z - sq_z, omz = 1.0f - z;
+    const T iden = M::rcp(vfma(st, z1mz, s));
+    const T inc = vfma(bh * vfma(s, sq_z, d0 * z1mz), iden, row.template get<K>(F_Y0L));
+    out = y0 + inc;
+    out_lo = inc - (out - y0);        // fast two-sum: |y0| >= |inc| except next to y0 = 0, where both are tiny
+    const T num2 = vfma(d1, sq_z, vfma(s * 2.0f, z1mz, d0 * omz * omz));
+    ld = row.template get<K>(F_L2S) + M::log(num2 * iden * iden);
+  } else {
+    rqs_bin_eval<INV, FAST, T>(v, row.template get<K>(F_X0), row.template get<K>(F_Y0), row.template get<K>(F_BW),
+                               row.template get<K>(F_BH), row.template get<K>(F_IBW),
+                               row.template get<K>(F_S), row.template get<K>(F_ST), row.template get<K>(F_D0),
+                               row.template get<K>(F_D1), row.template get<K>(F_L2S), out, ld);
+  }
   if (maybe_outside(v, sc.lo, sc.hi)) {   // linear tails (rare: |v| >= 10)
     const auto below = vle(v, sc.lo);
     const auto above = vge(v, sc.hi);
@@ -347,7 +368,14 @@ __device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab,
     ld = vsel(below, splat<T>(INV ? -tl[T_LOG_DLO] : tl[T_LOG_DLO]), ld);
     out = vsel(above, hi_out, out);
     ld = vsel(above, splat<T>(INV ? -tl[T_LOG_DHI] : tl[T_LOG_DHI]), ld);
+    if constexpr (PRECISE) out_lo = vsel(below, splat<T>(0.0f), vsel(above, splat<T>(0.0f), out_lo));
   }
+}
+template <int K, bool INV, bool FAST, class T>
+__device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab, T v,
+                                             const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld) {
+  T unused;
+  table_spline<K, INV, FAST, T, false>(tab, v, sc, out, ld, unused);
 }
 
 // ---------------------------------------------------------------------------
@@ -481,6 +509,147 @@ __device__ __forceinline__ void cond_spline(const T (&th)[3 * K + 1], T v,
     out = vsel(above, hi_out, out);
     ld = vsel(above, INV ? -ld1 : ld1, ld);
   }
+}
+
+// ---------------------------------------------------------------------------
+// Precise position path of the data -> base direction (spline FORWARD; log_prob,
+// inverse).  log_prob = sum -x^2/2 + ildj multiplies the error of the recovered
+// base point by |x| <= 5, and in plain fp32 that error is ~2e-6: the K softmax
+// terms carry ~1e-7 relative error each (v_exp_f32, the sum, the reciprocal) and
+// the knots are 20 x their prefix sums.  scripts/numerics/exp_logprob_precision.py
+// (float64 / float32 per stage on the CPU): normalisation + knot positions in
+// float64 with everything else (conditioner, slopes, log-det) in fp32 gives
+// 1e-6 .. 2.5e-6 max |d log_prob| on 65 536 samples; all-fp32 gives 1.1e-5 ..
+// 1.5e-5.  So here, per conditioner spline:
+//   * e_k = 2^(t_k) to ~1e-9 relative: t = -(idx / 32) + r, 2^(-idx/32) from a
+//     1 025-entry float64 table in LDS (t >= -32; smaller terms are below 2^-32
+//     of the largest), 2^r - 1 by a cubic in fp32 (|r| <= 1/64);
+//   * prefix sums, the total, the quotient S_k / E and the corner
+//     x0 = lo + k min_bin + span S_k / E in float64 (v_add_f64 / v_fma_f64 issue
+//     at the rate of unpacked fp32 on gfx950; a float-pair emulation costs 6-8
+//     fp32 operations per addition);
+//   * the offset in the bin (double)v - x0 and the result y0 + increment in
+//     float64, rounded once; the bin is chosen on the fp32-rounded knots (next to
+//     a knot either neighbour gives the same value: the spline is C1).
+// One sample at a time (sample pairs are split: no packed float64 exists).
+// ---------------------------------------------------------------------------
+constexpr int EXP2_STEPS = 32;                    // table points per unit exponent
+constexpr int EXP2_RANGE = 32;                    // exponents in [-32, 0]
+constexpr int EXP2_N = EXP2_STEPS * EXP2_RANGE + 1;      // doubles in the table: 2^(-i/32), i = 0 .. 1024
+constexpr float LOG2E_LO = 1.92596299112661746e-08f;     // log2(e) - (float)log2(e)
+
+__device__ __forceinline__ double exp2_precise(float t, float t_err, const double* e2tab) {
+  t = fmaxf(t, -(float)EXP2_RANGE);
+  const unsigned idx = (unsigned)fmaf(t, -(float)EXP2_STEPS, 0.5f);      // v_cvt_u32_f32 truncates: round to nearest
+  const float r = fmaf((float)idx, 1.0f / EXP2_STEPS, t) + t_err;       // exact up to t_err: |r| <= 1/64
+  const float p = r * fmaf(r, fmaf(r, 0.0555041086648215799f, 0.240226506959100712f), 0.693147180559945309f);
+  const double T = e2tab[idx];
+  return fma(T, (double)p, T);
+}
+
+typedef SplineConstsT<double> PreciseConsts;     // the float64 copy of the spline constants (ModelArgs::scd)
+
+// sum_d x_d^2 of the recovered base point in float64, from fp32 values and what their rounding dropped
+template <class T> struct BaseAcc;
+template <> struct BaseAcc<float> {
+  double b = 0.0;
+  __device__ __forceinline__ void add(float o, float lo) { const double x = (double)o + (double)lo; b = fma(x, x, b); }
+  __device__ __forceinline__ float log_prob(float ildj, int D) const {
+    return (float)(fma(-0.5, b, -(double)D * 0.91893853320467274178) + (double)ildj);
+  }
+};
+template <> struct BaseAcc<v2f> {
+  double bx = 0.0, by = 0.0;
+  __device__ __forceinline__ void add(v2f o, v2f lo) {
+    const double x = (double)o.x + (double)lo.x, y = (double)o.y + (double)lo.y;
+    bx = fma(x, x, bx); by = fma(y, y, by);
+  }
+  __device__ __forceinline__ v2f log_prob(v2f ildj, int D) const {
+    const double c = -(double)D * 0.91893853320467274178;
+    return v2f{(float)(fma(-0.5, bx, c) + (double)ildj.x), (float)(fma(-0.5, by, c) + (double)ildj.y)};
+  }
+};
+template <> struct BaseAcc<double> {       // (the float64 kernels never take the precise path)
+  __device__ __forceinline__ void add(double, double) {}
+  __device__ __forceinline__ double log_prob(double ildj, int) const { return ildj; }
+};
+
+// LOG2_UNITS: the 2K softmax logits are already in log2 units and the slope logits carry the softplus offset
+// (rows of the conditioner tables, cnf_pwl.h).  Returns out (fp32) and what its rounding dropped (`out_lo`).
+template <int K, bool FAST, bool LOG2_UNITS>
+__device__ __forceinline__ void cond_spline_precise(const float (&th)[3 * K + 1], float v, const SplineConsts& sc,
+                                                    const PreciseConsts& pc, const double* e2tab,
+                                                    float& out, float& ld, float& out_lo) {
+  using M = Math<FAST>;
+  float mw = th[0], mh = th[K];
+#pragma unroll
+  for (int k = 1; k < K; ++k) { mw = fmaxf(mw, th[k]); mh = fmaxf(mh, th[K + k]); }
+  double Sw[K + 1], Sh[K + 1];
+  float ew[K], eh[K];
+  Sw[0] = 0.0; Sh[0] = 0.0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float dw = th[k] - mw, dh = th[K + k] - mh;
+    float tw = dw, twe = 0.0f, tg = dh, tge = 0.0f;
+    if (!LOG2_UNITS) {
+      tw = dw * LOG2E; twe = fmaf(dw, LOG2E, -tw) + dw * LOG2E_LO;
+      tg = dh * LOG2E; tge = fmaf(dh, LOG2E, -tg) + dh * LOG2E_LO;
+    }
+    const double e_w = exp2_precise(tw, twe, e2tab), e_h = exp2_precise(tg, tge, e2tab);
+    ew[k] = (float)e_w; eh[k] = (float)e_h;
+    Sw[k + 1] = Sw[k] + e_w; Sh[k + 1] = Sh[k] + e_h;
+  }
+  // 1 / E: fp32 reciprocal, one Newton step in float64
+  double rw = (double)M::rcp((float)Sw[K]), rh = (double)M::rcp((float)Sh[K]);
+  rw = rw * fma(-Sw[K], rw, 2.0);
+  rh = rh * fma(-Sh[K], rh, 2.0);
+  const float aw = (float)rw * sc.span_eff, ah = (float)rh * sc.span_eff;
+  // bin on the fp32-rounded x knots; the selected bin's prefix sums, terms and slope logits by select chains
+  double Sw_sel = 0.0, Sh_sel = 0.0;
+  float ew_sel = ew[0], eh_sel = eh[0], t0 = th[2 * K], t1 = th[2 * K + 1];
+  int kk = 0;
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+    const float knot = fmaf((float)Sw[j], aw, sc.lo + (float)j * sc.min_bin);
+    const bool ge = v >= knot;
+    Sw_sel = ge ? Sw[j] : Sw_sel; Sh_sel = ge ? Sh[j] : Sh_sel;
+    ew_sel = ge ? ew[j] : ew_sel; eh_sel = ge ? eh[j] : eh_sel;
+    t0 = ge ? th[2 * K + j] : t0; t1 = ge ? th[2 * K + j + 1] : t1;
+    kk += ge ? 1 : 0;
+  }
+  const double base_k = fma((double)kk, pc.min_bin, pc.lo);
+  const double x0 = fma(pc.span_eff, Sw_sel * rw, base_k), y0 = fma(pc.span_eff, Sh_sel * rh, base_k);
+  const float bw = fmaf(ew_sel, aw, sc.min_bin), bh = fmaf(eh_sel, ah, sc.min_bin);
+  const float d0 = knot_slope<FAST, float, LOG2_UNITS>(t0, sc), d1 = knot_slope<FAST, float, LOG2_UNITS>(t1, sc);
+  const float ibw = M::rcp(bw);
+  const float s = bh * ibw, st = d1 + d0 - 2.0f * s;
+  const float z = clip01((float)((double)v - x0) * ibw);
+  const float sq_z = z * z, z1mz = z - sq_z, omz = 1.0f - z;
+  const float iden = M::rcp(fmaf(st, z1mz, s));
+  const float inc = bh * fmaf(s, sq_z, d0 * z1mz) * iden;
+  const double out_d = y0 + (double)inc;
+  out = (float)out_d;
+  out_lo = (float)(out_d - (double)out);
+  const float num2 = fmaf(d1, sq_z, fmaf(2.0f * s, z1mz, d0 * omz * omz));
+  const float q = s * iden;
+  ld = M::log(num2 * q * q);
+  if (maybe_outside(v, sc.lo, sc.hi)) {      // linear tails: bin 0 / bin K-1 were selected
+    if (v <= sc.lo) { out = fmaf(v - sc.lo, d0, sc.lo); ld = M::log(d0); out_lo = 0.0f; }
+    if (v >= sc.hi) { out = fmaf(v - sc.hi, d1, sc.hi); ld = M::log(d1); out_lo = 0.0f; }
+  }
+}
+
+template <int K, bool FAST, bool LOG2_UNITS>
+__device__ __forceinline__ void cond_spline_precise(const v2f (&th)[3 * K + 1], v2f v, const SplineConsts& sc,
+                                                    const PreciseConsts& pc, const double* e2tab,
+                                                    v2f& out, v2f& ld, v2f& out_lo) {
+  float tx[3 * K + 1], ty[3 * K + 1];
+#pragma unroll
+  for (int j = 0; j < 3 * K + 1; ++j) { tx[j] = th[j].x; ty[j] = th[j].y; }
+  float ox, lx, rx, oy, ly, ry;
+  cond_spline_precise<K, FAST, LOG2_UNITS>(tx, v.x, sc, pc, e2tab, ox, lx, rx);
+  cond_spline_precise<K, FAST, LOG2_UNITS>(ty, v.y, sc, pc, e2tab, oy, ly, ry);
+  out = v2f{ox, oy}; ld = v2f{lx, ly}; out_lo = v2f{rx, ry};
 }
 
 // ---------------------------------------------------------------------------

@@ -130,6 +130,8 @@ __global__ void prepare_kernel(const float* __restrict__ params, float* __restri
     prep[tab_off(F_D0, K) + k] = (float)dl[k];
     prep[tab_off(F_D1, K) + k] = (float)dl[k + 1];
     prep[tab_off(F_L2S, K) + k] = (float)(2.0 * log(s));
+    prep[tab_off(F_X0L, K) + k] = (float)(xk[k] - (double)(float)xk[k]);
+    prep[tab_off(F_Y0L, K) + k] = (float)(yk[k] - (double)(float)yk[k]);
   }
   for (int k = 0; k <= K; ++k) {
     prep[tab_off(F_XK, K) + k] = (float)xk[k];
@@ -207,10 +209,14 @@ __device__ __forceinline__ v2f hsum(v2f v) { return v; }
 // TO_BASE=true : data -> base (chain.forward, spline forward, conditions on
 // already-produced outputs: conditional.py:159-167, autoregressive.py:76-107).
 // Returns the accumulated log|det J|; the result is left in `U` (swapped).
-template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false>
+// PRECISE (TO_BASE only): the precise position path of cnf_device.h; `e2tab` is its 2^(-i/32) table in LDS and
+// `bacc` receives sum_d x_d^2 of the recovered base point in float64.
+template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false, bool PRECISE = false>
 __device__ __forceinline__ T flow_pass(const ModelArgs& a, const typename Lanes<T>::real* tab,
-                                       typename Lanes<T>::real*& U, typename Lanes<T>::real*& O, T c) {
+                                       typename Lanes<T>::real*& U, typename Lanes<T>::real*& O, T c,
+                                       const double* e2tab = nullptr, BaseAcc<T>* bacc = nullptr) {
   typedef typename Lanes<T>::real R;
+  static_assert(!PRECISE || (TO_BASE && !std::is_same<T, double>::value), "precise path: data -> base, fp32 kernels");
   const SplineConstsT<R>& sc = sc_of<R>(a);
   static_assert(!MFMA || (H == 16 && K == 5), "the MFMA conditioner is built for H = 16, P = 16");
   constexpr int P = 3 * K + 1;
@@ -226,10 +232,12 @@ __device__ __forceinline__ T flow_pass(const ModelArgs& a, const typename Lanes<
     const int first_idx = odd ? D - 1 : 0, idx_step = odd ? -1 : 1;
     R* cu = U + SPL * threadIdx.x;
     R* co = O + SPL * threadIdx.x;
-    T o, ld;
-    table_spline<K, INV, FAST, T>(tab, lds_get<T>(cu, first_idx, TS), sc, o, ld);
+    T o, ld, olo;
+    table_spline<K, INV, FAST, T, PRECISE>(tab, lds_get<T>(cu, first_idx, TS), sc, o, ld, olo);
     lds_put(co, first_idx, TS, o);
     acc += ld;
+    const bool last = step == a.L - 1;
+    if constexpr (PRECISE) { if (last) bacc->add(o, olo); }
     uniform_ptr w = weights + l * a.per_layer;
     const float* wq = a.wq + l * a.per_layer_q;
     for (int d = 1; d < D; ++d) {
@@ -242,7 +250,12 @@ __device__ __forceinline__ T flow_pass(const ModelArgs& a, const typename Lanes<
         conditioner<H, P, T>(w, d, a.M, c, TO_BASE ? co : cu, first_idx, idx_step, TS, th);
         w += cond_floats(d, H, a.M, P);
       }
-      cond_spline<K, INV, FAST, T>(th, lds_get<T>(cu, i, TS), sc, o, ld);
+      if constexpr (PRECISE) {
+        cond_spline_precise<K, FAST, false>(th, lds_get<T>(cu, i, TS), sc, a.scd, e2tab, o, ld, olo);
+        if (last) bacc->add(o, olo);
+      } else {
+        cond_spline<K, INV, FAST, T>(th, lds_get<T>(cu, i, TS), sc, o, ld);
+      }
       lds_put(co, i, TS, o);
       acc += ld;
     }
@@ -270,7 +283,7 @@ __device__ __forceinline__ void store_aux(float* aux, int64_t i, int64_t B, v2f 
   else { if (i < B) aux[i] = r.x; if (i + 1 < B) aux[i + 1] = r.y; }
 }
 
-template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false>
+template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false, bool PRECISE = false>
 __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename Lanes<T>::real> a) {
   typedef typename Lanes<T>::real R;
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
@@ -282,6 +295,11 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
   R* U = lds + HDR;
   R* O = U + a.m.D * TS;
   for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = table_of<R>(a.m)[i];
+  double* e2tab = nullptr;
+  if constexpr (PRECISE) {                 // [.. U O][2^(-i/32) table]; HDR and D * TS are even: 8-byte aligned
+    e2tab = reinterpret_cast<double*>(O + a.m.D * TS);
+    for (int i = threadIdx.x; i < EXP2_N; i += TILE) e2tab[i] = a.m.e2tab[i];
+  }
 
   const int64_t n_tiles = (a.B + TS - 1) / TS;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -294,12 +312,14 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
 
     T base = splat<T>(0.0f);
     if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = base_logprob<T>(U + SPL * threadIdx.x, a.m.D, TS);
-    const T acc = flow_pass<H, K, TO_BASE, FAST, T, MFMA>(a.m, tab, U, O, c);
+    BaseAcc<T> bacc;
+    const T acc = flow_pass<H, K, TO_BASE, FAST, T, MFMA, PRECISE>(a.m, tab, U, O, c, e2tab, &bacc);
     if (a.aux) {
       T r = acc;
       if (a.aux_mode == AUX_LOGPROB) {
         // log_prob = base(x) + ildj (conditional.py:316-321); lp_y = lp_x - fldj (:399-401)
-        r = TO_BASE ? base_logprob<T>(U + SPL * threadIdx.x, a.m.D, TS) + acc : base - acc;
+        if constexpr (PRECISE) r = bacc.log_prob(acc, a.m.D);
+        else r = TO_BASE ? base_logprob<T>(U + SPL * threadIdx.x, a.m.D, TS) + acc : base - acc;
       }
       store_aux(a.aux, i, a.B, r);
     }
@@ -346,21 +366,30 @@ __device__ __forceinline__ void pwl_stage(float* tbl, const float* __restrict__ 
 // The dim-2 flow on one sample pair held in registers, conditioner from the tables (`tbl`: the L
 // tables in LDS, `gtbl`: the same in global memory for rows past the LDS window).  In place;
 // returns the accumulated log|det J| of the direction.
-template <int K, bool TO_BASE, bool FAST>
+template <int K, bool TO_BASE, bool FAST, bool PRECISE = false>
 __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, const float* __restrict__ gtbl,
-                                            int L, const SplineConsts& sc, v2f& u0, v2f& u1) {
+                                            int L, const SplineConsts& sc, v2f& u0, v2f& u1,
+                                            const PreciseConsts* pc = nullptr, const double* e2tab = nullptr,
+                                            BaseAcc<v2f>* bacc = nullptr) {
   constexpr bool INV = !TO_BASE;
+  static_assert(!PRECISE || TO_BASE, "precise path: data -> base");
   v2f acc = splat<v2f>(0.0f);
   for (int step = 0; step < L; ++step) {
     const int l = TO_BASE ? L - 1 - step : step;
     const bool odd = l & 1;                     // flows.py:141-143 perms
     const v2f uf = odd ? u1 : u0, uo = odd ? u0 : u1;
-    v2f of, oo, ld;
-    table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld);
+    v2f of, oo, ld, olo;
+    table_spline<K, INV, FAST, v2f, PRECISE>(tab, uf, sc, of, ld, olo);
     acc += ld;
+    if constexpr (PRECISE) { if (step == L - 1) bacc->add(of, olo); }
     v2f th[PWL_P];
     pwl_eval(tbl + l * PWL_LTBL, gtbl + (int64_t)l * PWL_TBL, TO_BASE ? of : uf, th);
-    cond_spline_masked<K, INV, FAST>(th, uo, sc, oo, ld);
+    if constexpr (PRECISE) {
+      cond_spline_precise<K, FAST, true>(th, uo, sc, *pc, e2tab, oo, ld, olo);
+      if (step == L - 1) bacc->add(oo, olo);
+    } else {
+      cond_spline_masked<K, INV, FAST>(th, uo, sc, oo, ld);
+    }
     acc += ld;
     u0 = odd ? oo : of;
     u1 = odd ? of : oo;
@@ -368,7 +397,7 @@ __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, 
   return acc;
 }
 
-template <int K, bool TO_BASE, bool FAST>
+template <int K, bool TO_BASE, bool FAST, bool PRECISE = false>
 __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs a) {
   const int PWL_THREADS = blockDim.x, PWL_TS = 2 * PWL_THREADS;
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
@@ -379,6 +408,11 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
   const int L = a.m.L;
   for (int i = tid; i < hdr_floats(K); i += PWL_THREADS) tab[i] = table_of<float>(a.m)[i];
   const SplineConsts& sc = sc_of<float>(a.m);
+  double* e2tab = nullptr;
+  if constexpr (PRECISE) {                 // after the L tables (HDR and PWL_LTBL are even: 8-byte aligned)
+    e2tab = reinterpret_cast<double*>(tbl + L * PWL_LTBL);
+    for (int i = tid; i < EXP2_N; i += PWL_THREADS) e2tab[i] = a.m.e2tab[i];
+  }
 
   const int total = a.n_slices * a.tiles_per_slice;
   const int per_block = (total + gridDim.x - 1) / gridDim.x;
@@ -405,10 +439,13 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
 
     v2f base = splat<v2f>(0.0f);
     if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = (u0 * u0 + u1 * u1) * -0.5f - (float)(2 * HALF_LOG_2PI);
-    const v2f acc = flow2_tables<K, TO_BASE, FAST>(tab, tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, sc, u0, u1);
+    BaseAcc<v2f> bacc;
+    const v2f acc = flow2_tables<K, TO_BASE, FAST, PRECISE>(tab, tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, sc,
+                                                            u0, u1, &a.m.scd, e2tab, &bacc);
     if (a.aux) {
       v2f r = acc;
-      if (a.aux_mode == AUX_LOGPROB)
+      if constexpr (PRECISE) { if (a.aux_mode == AUX_LOGPROB) r = bacc.log_prob(acc, 2); }
+      else if (a.aux_mode == AUX_LOGPROB)
         r = TO_BASE ? (u0 * u0 + u1 * u1) * -0.5f - (float)(2 * HALF_LOG_2PI) + acc : base - acc;
       if (v1) *reinterpret_cast<v2f*>(a.aux + g) = r;
       else if (v0) a.aux[g] = r.x;
@@ -865,14 +902,36 @@ extern "C" int cnf_model_create(const CnfConfig* cfg, CnfModel** out) {
   }
   // float64 copy of the `first` table (exact-mode kernels), 8-byte aligned, after everything else
   m->tabd_off = (hdr_floats(K) + (m->n_params - P) + 4 + (int64_t)q_floats + 1) & ~(int64_t)1;
-  const size_t bytes = (size_t)(m->tabd_off + 2 * hdr_floats(K)) * sizeof(float) + 64;
+  // 2^(-i/32), i = 0 .. 1024, float64: the table of the precise position path (cnf_device.h)
+  m->e2_off = m->tabd_off + 2 * hdr_floats(K);
+  m->precise = 1;
+  const size_t bytes = (size_t)(m->e2_off + 2 * cnf::EXP2_N) * sizeof(float) + 64;
   m->scd.lo = (double)cfg->range_min; m->scd.hi = (double)cfg->range_max;
   m->scd.min_bin = (double)cfg->min_bin_size; m->scd.min_slope = (double)cfg->min_knot_slope;
   m->scd.span_eff = (m->scd.hi - m->scd.lo) - (double)K * m->scd.min_bin;
   m->scd.sp_offset = log(exp(1.0 - m->scd.min_slope) - 1.0);
   if (hipMalloc((void**)&m->prep, bytes) != hipSuccess) { delete m; return CNF_ERR_NOMEM; }
+  {
+    double e2[cnf::EXP2_N];
+    for (int i = 0; i < cnf::EXP2_N; ++i) e2[i] = exp2(-(double)i / (double)cnf::EXP2_STEPS);
+    if (hipMemcpy(m->prep + m->e2_off, e2, sizeof(e2), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(m->prep); delete m; return CNF_ERR_HIP;
+    }
+  }
+  if (hipEventCreateWithFlags(&m->prep_event, hipEventDisableTiming) != hipSuccess) {
+    (void)hipFree(m->prep); delete m; return CNF_ERR_HIP;
+  }
   *out = m;
   return CNF_OK;
+}
+
+static void prof_clear(CnfModel* m) {
+  for (auto& r : m->prof) {
+    if (r.e0) (void)hipEventDestroy(r.e0);
+    if (r.e1) (void)hipEventDestroy(r.e1);
+    if (r.e2) (void)hipEventDestroy(r.e2);
+  }
+  m->prof.clear();
 }
 
 extern "C" void cnf_model_destroy(CnfModel* m) {
@@ -880,8 +939,61 @@ extern "C" void cnf_model_destroy(CnfModel* m) {
   if (m->prep) (void)hipFree(m->prep);
   if (m->grad_slabs) (void)hipFree(m->grad_slabs);
   for (auto& kv : m->pwl_ws) if (kv.second.tables) (void)hipFree(kv.second.tables);
+  if (m->prep_event) (void)hipEventDestroy(m->prep_event);
+  prof_clear(m);
   delete m;
 }
+
+/* Which kernels the most recent compute call of this model ran: a CnfPath value (cnf_common.h).
+ * Tests use it to assert that a forced path was really taken; bench.py labels its roofline with it. */
+extern "C" int cnf_model_last_path(const CnfModel* m) { return m ? m->last_path : CNF_ERR_INVALID; }
+
+/* Internal (bench.py): with profiling on, the flow entry points record HIP events around their kernels
+ * (table path: before the table build, between build and flow kernel, after the flow kernel), at most
+ * 4096 launches.  cnf_model_read_profile waits for them and returns the SUMS in milliseconds of the
+ * dominant (flow) kernel and of the table build, the number of kernel launches and the samples they
+ * processed, then clears the records. */
+extern "C" int cnf_model_set_profiling(CnfModel* m, int on) {
+  if (!m) return CNF_ERR_INVALID;
+  m->profiling = on ? 1 : 0;
+  if (!on) prof_clear(m);
+  return CNF_OK;
+}
+
+extern "C" int cnf_model_read_profile(CnfModel* m, double* flow_ms, double* build_ms, int64_t* launches,
+                                      int64_t* samples) {
+  if (!m) return CNF_ERR_INVALID;
+  double f = 0.0, b = 0.0;
+  int64_t n = 0, smp = 0;
+  for (auto& r : m->prof) {
+    if (hipEventSynchronize(r.e2) != hipSuccess) return CNF_ERR_HIP;
+    float ms = 0.f;
+    if (r.e0) { if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return CNF_ERR_HIP; b += ms; }
+    if (hipEventElapsedTime(&ms, r.e1, r.e2) != hipSuccess) return CNF_ERR_HIP;
+    f += ms; ++n; smp += r.samples;
+  }
+  prof_clear(m);
+  if (flow_ms) *flow_ms = f;
+  if (build_ms) *build_ms = b;
+  if (launches) *launches = n;
+  if (samples) *samples = smp;
+  return CNF_OK;
+}
+
+// profiling helpers: a record is opened before the (optional) build kernel and closed after the flow kernel
+struct ProfScope {
+  CnfModel* m; hipStream_t s; CnfModel::ProfRec r; bool on;
+  ProfScope(CnfModel* m_, hipStream_t s_, bool with_build, int64_t samples, int path) : m(m_), s(s_), on(false) {
+    r.e0 = r.e1 = r.e2 = nullptr; r.samples = samples; r.path = path;
+    if (!m->profiling || m->prof.size() >= 4096) return;
+    if (hipEventCreate(&r.e1) != hipSuccess || hipEventCreate(&r.e2) != hipSuccess) return;
+    if (with_build) { if (hipEventCreate(&r.e0) != hipSuccess) return; (void)hipEventRecord(r.e0, s); }
+    else (void)hipEventRecord(r.e1, s);
+    on = true;
+  }
+  void built() { if (on && r.e0) (void)hipEventRecord(r.e1, s); }
+  void done() { if (on) { (void)hipEventRecord(r.e2, s); m->prof.push_back(r); on = false; } }
+};
 
 /* Internal knob used by the tests and the bench: 1 = hardware transcendentals
  * (default), 0 = ocml expf/logf/sqrtf + IEEE division. */
@@ -906,6 +1018,14 @@ extern "C" int cnf_model_set_pwl(CnfModel* m, int mode) {
   return CNF_OK;
 }
 
+/* 1 (default): cnf_log_prob / cnf_inverse_logdet (data -> base) carry the knot positions, the offset in the
+ * bin and the base term in float64 (cnf_device.h "precise position path"); 0: plain fp32 throughout. */
+extern "C" int cnf_model_set_precise(CnfModel* m, int on) {
+  if (!m) return CNF_ERR_INVALID;
+  m->precise = on ? 1 : 0;
+  return CNF_OK;
+}
+
 /* Internal knob: 0 = choose by batch size, 1 / 2 = force samples per lane. */
 extern "C" int cnf_model_set_samples_per_lane(CnfModel* m, int spl) {
   if (!m || spl < 0 || spl > 2) return CNF_ERR_INVALID;
@@ -926,6 +1046,8 @@ extern "C" int cnf_model_set_params(CnfModel* m, const float* params, void* stre
                      m->cfg.num_layers, m->cfg.mlp_num_layers, m->per_layer, m->per_layer_q, m->mfma_off,
                      m->tabd_off);
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
+  if (hipEventRecord(m->prep_event, (hipStream_t)stream) != hipSuccess) return CNF_ERR_HIP;
+  m->prep_stream = stream;
   m->params_set = 1;
   return CNF_OK;
 }
@@ -951,17 +1073,37 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
   int64_t grid = n_tiles;
   const int64_t cap = (int64_t)m->num_cus * 8;
   if (grid > cap) grid = cap;
-  const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * ts) * sizeof(float);
+  constexpr bool PR = TO_BASE;                 // the precise position path exists for the data -> base direction
+  const bool precise = PR && m->precise;
+  const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * ts) * sizeof(float) +
+                     (precise ? sizeof(double) * cnf::EXP2_N : 0);
   if (m->fast_math && m->use_mfma && m->mfma_off > 0 && m->cfg.hidden_size == 16 && m->cfg.num_bins == 5) {
-    if (spl == 2) CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, v2f, true>), grid, lds, stream, a);
-    else CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, float, true>), grid, lds, stream, a);
+    m->last_path = CNF_PATH_MFMA;
+    ProfScope ps(m, stream, false, a.B, CNF_PATH_MFMA);
+    if (precise) {
+      if (spl == 2) CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, v2f, true, PR>), grid, lds, stream, a);
+      else CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, float, true, PR>), grid, lds, stream, a);
+    } else {
+      if (spl == 2) CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, v2f, true>), grid, lds, stream, a);
+      else CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, float, true>), grid, lds, stream, a);
+    }
+    ps.done();
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
   }
+  m->last_path = spl == 2 ? CNF_PATH_MLP2 : CNF_PATH_MLP1;
+  ProfScope ps(m, stream, false, a.B, m->last_path);
 #define X(HH, KK)                                                                             \
   if (m->cfg.hidden_size == HH && m->cfg.num_bins == KK) {                                    \
-    if (!m->fast_math) CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, false, float>), grid, lds, stream, a);        \
-    else if (spl == 2) CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, true, v2f>), grid, lds, stream, a);           \
-    else CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, true, float>), grid, lds, stream, a);                       \
+    if (precise) {                                                                            \
+      if (!m->fast_math) CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, false, float, false, PR>), grid, lds, stream, a);  \
+      else if (spl == 2) CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, true, v2f, false, PR>), grid, lds, stream, a);     \
+      else CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, true, float, false, PR>), grid, lds, stream, a);                 \
+    } else {                                                                                  \
+      if (!m->fast_math) CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, false, float>), grid, lds, stream, a);      \
+      else if (spl == 2) CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, true, v2f>), grid, lds, stream, a);         \
+      else CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, true, float>), grid, lds, stream, a);                     \
+    }                                                                                         \
+    ps.done();                                                                                \
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;                            \
   }
   CNF_KERNEL_CONFIGS(X)
@@ -969,24 +1111,43 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
   return CNF_ERR_UNSUPPORTED;
 }
 
-// This stream's table workspace, large enough for `n_slices` slices (x L tables); grown when a call needs
-// more than any before on the stream (the only allocation a compute entry point can make: warm up once
-// before capturing a graph).
-static int pwl_workspace(CnfModel* m, hipStream_t stream, int64_t n_slices, float** out) {
+// This stream's table workspace (cnf_model_reserve).  Lookup only: the compute entry points never allocate,
+// free or synchronise.  *sets = 0 when the stream has no reservation.
+static void pwl_workspace(CnfModel* m, hipStream_t stream, float** tables, int64_t* sets) {
   std::lock_guard<std::mutex> lock(m->pwl_mu);
-  CnfModel::PwlWorkspace& ws = m->pwl_ws[(void*)stream];          // value-initialised on first use
-  if (ws.slices < n_slices) {
-    if (ws.tables) {
-      if (hipStreamSynchronize(stream) != hipSuccess) return CNF_ERR_HIP;
-      (void)hipFree(ws.tables);
-      ws.tables = nullptr; ws.slices = 0;
-    }
-    if (hipMalloc((void**)&ws.tables, sizeof(float) * (size_t)n_slices * m->cfg.num_layers * cnf::PWL_TBL) != hipSuccess)
-      return CNF_ERR_NOMEM;
-    ws.slices = n_slices;
+  auto it = m->pwl_ws.find((void*)stream);
+  if (it == m->pwl_ws.end()) { *tables = nullptr; *sets = 0; return; }
+  *tables = it->second.tables; *sets = it->second.sets;
+}
+
+extern "C" int64_t cnf_model_table_bytes(const CnfModel* m) {
+  return m ? (int64_t)sizeof(float) * m->cfg.num_layers * cnf::PWL_TBL : 0;
+}
+
+extern "C" int cnf_model_reserve(CnfModel* m, void* stream, int64_t n_sets) {
+  if (!m || n_sets < 0) return CNF_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(m->pwl_mu);
+  CnfModel::PwlWorkspace& ws = m->pwl_ws[stream];          // value-initialised on first use
+  if (ws.sets >= n_sets && n_sets > 0) return CNF_OK;
+  if (ws.tables) {
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return CNF_ERR_HIP;   // kernels may still read it
+    (void)hipFree(ws.tables);
+    ws.tables = nullptr; ws.sets = 0;
   }
-  *out = ws.tables;
+  if (n_sets == 0) { m->pwl_ws.erase(stream); return CNF_OK; }
+  if (hipMalloc((void**)&ws.tables, (size_t)cnf_model_table_bytes(m) * (size_t)n_sets) != hipSuccess) {
+    m->pwl_ws.erase(stream);
+    return CNF_ERR_NOMEM;
+  }
+  ws.sets = n_sets;
   return CNF_OK;
+}
+
+extern "C" int64_t cnf_model_reserved(CnfModel* m, void* stream) {
+  if (!m) return CNF_ERR_INVALID;
+  float* t; int64_t sets;
+  pwl_workspace(m, (hipStream_t)stream, &t, &sets);
+  return sets;
 }
 
 static const int64_t PWL_MAX_SLICES = 2048;      // slices per build + flow kernel pair
@@ -1004,7 +1165,9 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
                         float* out, float* aux, int aux_mode, int64_t B, hipStream_t stream) {
   if (!pwl_config_ok(m)) return CNF_ERR_UNSUPPORTED;
   const int L = m->cfg.num_layers;
-  size_t lds = (size_t)(((cnf::hdr_floats(5) + 3) & ~3) + L * cnf::PWL_LTBL) * sizeof(float);
+  const bool precise = to_base && m->precise;
+  size_t lds = (size_t)(((cnf::hdr_floats(5) + 3) & ~3) + L * cnf::PWL_LTBL) * sizeof(float) +
+               (precise ? sizeof(double) * cnf::EXP2_N : 0);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
   const int64_t slice_len = c_block < B ? c_block : B;
   const int64_t n_slices = (B + slice_len - 1) / slice_len;
@@ -1026,22 +1189,31 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
   // (crossover with the MLP kernel: B / 26 G/s = 20 us of table building + B / 62 G/s  ->  B ~ 0.9 M samples)
   if (m->use_pwl == 1 && (total < 2 * (int64_t)m->num_cus || slice_len < 4 * PWL_TS)) return CNF_ERR_UNSUPPORTED;
   if (pwl_min_lds > lds) lds = pwl_min_lds;
-  if (to_base ? !ensure_lds(cnf::flow_pwl_kernel<5, true, true>, lds) : !ensure_lds(cnf::flow_pwl_kernel<5, false, true>, lds))
+  if (precise ? !ensure_lds(cnf::flow_pwl_kernel<5, true, true, true>, lds)
+              : (to_base ? !ensure_lds(cnf::flow_pwl_kernel<5, true, true>, lds)
+                         : !ensure_lds(cnf::flow_pwl_kernel<5, false, true>, lds)))
     return CNF_ERR_UNSUPPORTED;
   // at most PWL_MAX_SLICES slices per kernel pair: the workspace stays bounded (2 048 x L x 46 KB) however many
   // slices a call has
-  const int64_t chunk = n_slices < PWL_MAX_SLICES ? n_slices : PWL_MAX_SLICES;
+  int64_t chunk = n_slices < PWL_MAX_SLICES ? n_slices : PWL_MAX_SLICES;
   float* tables = nullptr;
   {
-    const int r = pwl_workspace(m, stream, chunk, &tables);
-    if (r != CNF_OK) return r;
+    // the stream's reservation decides: none (or one too small to keep every CU busy) -> the MLP kernel
+    int64_t sets = 0;
+    pwl_workspace(m, stream, &tables, &sets);
+    if (sets < chunk) chunk = sets;
+    if (chunk < 1) return CNF_ERR_UNSUPPORTED;
+    if (m->use_pwl == 1 && chunk < n_slices && chunk * tps < (int64_t)m->num_cus) return CNF_ERR_UNSUPPORTED;
   }
   const double sp_offset = log(exp(1.0 - (double)m->cfg.min_knot_slope) - 1.0);
+  m->last_path = CNF_PATH_TABLES;
   for (int64_t s0 = 0; s0 < n_slices; s0 += chunk) {
     const int64_t ns = n_slices - s0 < chunk ? n_slices - s0 : chunk;
     const int64_t first = s0 * slice_len;
+    ProfScope ps(m, stream, true, (B - first) < ns * slice_len ? (B - first) : ns * slice_len, CNF_PATH_TABLES);
     hipLaunchKernelGGL(cnf::pwl_build_kernel, dim3((unsigned)(ns * L)), dim3(512), 0, stream,
                        (const float*)(m->prep + cnf::hdr_floats(5)), m->per_layer, c + s0, 0.0f, L, sp_offset, tables);
+    ps.built();
     cnf::PwlArgs a;
     a.m = model_args(m);
     a.in = in + first * 2; a.out = out ? out + first * 2 : nullptr; a.aux = aux ? aux + first : nullptr;
@@ -1051,10 +1223,13 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
     a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps; a.aux_mode = aux_mode;
     const int64_t tiles = ns * tps;
     const int64_t grid = tiles < m->num_cus ? tiles : m->num_cus;
-    if (to_base)
+    if (precise)
+      hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, true, true, true>), dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
+    else if (to_base)
       hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, true, true>), dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
     else
       hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, false, true>), dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
+    ps.done();
   }
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
@@ -1065,6 +1240,7 @@ static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, 
   if (!out && !aux) return CNF_ERR_INVALID;
   if (!m->params_set) return CNF_ERR_INVALID;
   if (B == 0) return CNF_OK;
+  if (wait_for_params(m, (hipStream_t)stream) != CNF_OK) return CNF_ERR_HIP;
   {
     const int r = run_flow_pwl(m, to_base, in, c, c_block, out, aux, aux_mode, B, (hipStream_t)stream);
     if (r != CNF_ERR_UNSUPPORTED) return r;
@@ -1077,7 +1253,8 @@ static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, 
   a.div_magic = m->div_magic;
   int spl = m->fast_math ? samples_per_lane(m, B) : 1;
   // two samples per lane double the LDS tile: fall back when it would not fit
-  if (spl == 2 && (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * TILE * 2) * sizeof(float) > 160 * 1024) spl = 1;
+  if (spl == 2 && (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * TILE * 2) * sizeof(float) +
+                      sizeof(double) * cnf::EXP2_N > 160 * 1024) spl = 1;
   if (c_block >= B) a.c_mode = C_SINGLE;
   else if (c_block == 1) a.c_mode = C_PER_SAMPLE;
   else if (c_block % (TILE * spl) == 0) a.c_mode = C_TILE_UNIFORM;
@@ -1139,13 +1316,17 @@ static int loss_terms_pwl(CnfModel* m, const CnfLossSpec* spec, const float* pts
   if (total > (1 << 30)) return CNF_ERR_UNSUPPORTED;
   if (m->use_pwl == 1 && (total < 2 * (int64_t)m->num_cus || B < 4 * ts)) return CNF_ERR_UNSUPPORTED;
   if (!ensure_lds(cnf::loss_pwl_kernel<5, true>, lds)) return CNF_ERR_UNSUPPORTED;
-  const int64_t chunk = n_slices < PWL_MAX_SLICES ? n_slices : PWL_MAX_SLICES;
+  int64_t chunk = n_slices < PWL_MAX_SLICES ? n_slices : PWL_MAX_SLICES;
   float* tables = nullptr;
   {
-    const int r = pwl_workspace(m, stream, chunk * n_sets, &tables);
-    if (r != CNF_OK) return r;
+    int64_t sets = 0;
+    pwl_workspace(m, stream, &tables, &sets);
+    if (sets / n_sets < chunk) chunk = sets / n_sets;
+    if (chunk < 1) return CNF_ERR_UNSUPPORTED;
+    if (m->use_pwl == 1 && chunk < n_slices && chunk * tps < (int64_t)m->num_cus) return CNF_ERR_UNSUPPORTED;
   }
   const double sp_offset = log(exp(1.0 - (double)m->cfg.min_knot_slope) - 1.0);
+  m->last_path = CNF_PATH_LOSS_TABLES;
   for (int64_t s0 = 0; s0 < n_slices; s0 += chunk) {
     const int64_t ns = n_slices - s0 < chunk ? n_slices - s0 : chunk;
     const int64_t set_stride = ns * L * (int64_t)cnf::PWL_TBL;
@@ -1192,10 +1373,12 @@ static int loss_terms_impl(CnfModel* m, const CnfLossSpec* spec, const float* pt
   if (n_slices == 0) return CNF_OK;
   if (hipMemsetAsync(sums, 0, sizeof(double) * (size_t)n_slices, stream) != hipSuccess) return CNF_ERR_HIP;
   if (B == 0) return CNF_OK;
+  if (wait_for_params(m, stream) != CNF_OK) return CNF_ERR_HIP;
   {
     const int r = loss_terms_pwl(m, spec, pts, slice_stride, seed, first_sample, t, n_slices, B, sums, stream);
     if (r != CNF_ERR_UNSUPPORTED) return r;
   }
+  m->last_path = CNF_PATH_LOSS_MLP;
 
   LossArgs a;
   a.m = model_args(m); a.spec = *spec; a.pts = pts; a.t = t; a.sums = sums;
@@ -1263,6 +1446,8 @@ static int run_flow_f64(CnfModel* m, bool to_base, const double* in, const doubl
   if (!out && !aux) return CNF_ERR_INVALID;
   if (!m->params_set) return CNF_ERR_INVALID;
   if (B == 0) return CNF_OK;
+  if (wait_for_params(m, (hipStream_t)stream) != CNF_OK) return CNF_ERR_HIP;
+  m->last_path = CNF_PATH_F64;
   FlowArgsD a;
   a.m = model_args(m);
   a.in = in; a.c = c; a.out = out; a.aux = aux;

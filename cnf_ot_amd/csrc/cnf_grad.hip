@@ -569,6 +569,7 @@ extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const f
   if (hipMemsetAsync(sums, 0, sizeof(double) * (size_t)n_slices, stream) != hipSuccess) return CNF_ERR_HIP;
   if (B == 0) return CNF_OK;
   if (!m->grad_slabs) return CNF_ERR_INVALID;      // cnf_grad_enable first
+  if (wait_for_params(m, stream) != CNF_OK) return CNF_ERR_HIP;
 
   GradArgs a;
   a.m = model_args(m); a.spec = *spec; a.pts = pts; a.t = t; a.sums = sums;
@@ -582,10 +583,10 @@ extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const f
   const int64_t n_slabs = grid * 4;
   if (hipMemsetAsync(m->grad_slabs, 0, sizeof(float) * (size_t)(n_slabs * m->n_params), stream) != hipSuccess) return CNF_ERR_HIP;
   if (m->fast_math) {
-    if (hipFuncSetAttribute((const void*)grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CNF_ERR_HIP;
+    if (!ensure_lds(grad_kernel<true>, lds)) return CNF_ERR_HIP;
     hipLaunchKernelGGL(grad_kernel<true>, dim3((unsigned)grid), dim3(TILE), lds, stream, a);
   } else {
-    if (hipFuncSetAttribute((const void*)grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CNF_ERR_HIP;
+    if (!ensure_lds(grad_kernel<false>, lds)) return CNF_ERR_HIP;
     hipLaunchKernelGGL(grad_kernel<false>, dim3((unsigned)grid), dim3(TILE), lds, stream, a);
   }
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
@@ -626,6 +627,7 @@ static int pass_vjp_impl(CnfModel* m, int to_base, const float* pts, const float
   if (B == 0) return CNF_OK;
   if (grad && !m->grad_slabs) return CNF_ERR_INVALID;      // cnf_grad_enable first
   hipStream_t stream = (hipStream_t)stream_;
+  if (wait_for_params(m, stream) != CNF_OK) return CNF_ERR_HIP;
   VjpArgs a;
   a.m = model_args(m); a.pts = pts; a.c = c; a.ybar = ybar; a.ldbar = ldbar; a.xbar = xbar;
   a.slabs = m->grad_slabs; a.n_params = m->n_params;

@@ -71,6 +71,10 @@ class FlowEngine:
                   "cnf_model_create")
     self._h = handle
     self._flat = None                 # keeps the caller's flat tensor alive
+    self._flat_key = None
+    self._reserved = {}               # stream -> table sets reserved (cnf_model_reserve)
+    self._pwl_mode = 1
+    self._tables_ok = (cfg.dim == 2 and cfg.hidden_size == 16 and cfg.num_bins == 5 and cfg.mlp_num_layers == 2)
 
   def __del__(self):
     h = getattr(self, "_h", None)
@@ -83,13 +87,56 @@ class FlowEngine:
 
   # -- parameters ------------------------------------------------------------
   def load(self, params) -> "FlowEngine":
-    """cnf_model_set_params: prepare the `first` table + snapshot the weights."""
+    """cnf_model_set_params: prepare the `first` table + snapshot the weights.
+    Skipped when `params` is the very tensor that is already loaded and nothing
+    has written to it since (torch's version counter; in-place writers that
+    bypass torch -- Adam.apply through the C ABI -- call `mark_updated`)."""
     flat = flatten(self.cfg, params, self.device)
+    key = (flat._version, getattr(flat, "_cnf_epoch", 0))
+    if flat is self._flat and key == self._flat_key:
+      return self
     with torch.cuda.device(self.device):
       _capi.check(self.lib.cnf_model_set_params(self._h, flat.data_ptr(), _stream_ptr(self.device)),
                   "cnf_model_set_params")
     self._flat = flat
+    self._flat_key = key
     return self
+
+  def reserve(self, n_slices: int, sets_per_slice: int = 1) -> int:
+    """cnf_model_reserve for the current stream: room for the conditioner
+    tables of `n_slices` time-slices (x sets_per_slice conditions; a call with
+    more slices than 2 048 is processed in chunks of that).  Allocates, so it is
+    skipped while the stream is being captured into a graph (the call then uses
+    what is reserved, or the MLP kernels).  Returns the sets now reserved."""
+    if not self._tables_ok:
+      return 0
+    stream = _stream_ptr(self.device)
+    have = self._reserved.get(stream, 0)
+    want = min(int(n_slices), 2048) * int(sets_per_slice)
+    if want <= have or torch.cuda.is_current_stream_capturing():
+      return have
+    want = max(16, 1 << (want - 1).bit_length())          # grow geometrically: few re-allocations
+    with torch.cuda.device(self.device):
+      _capi.check(self.lib.cnf_model_reserve(self._h, stream, want), "cnf_model_reserve")
+    self._reserved[stream] = want
+    return want
+
+  def last_path(self) -> str:
+    """Which kernels the most recent compute call ran (cnf_model_last_path)."""
+    return _capi.PATH_NAMES.get(self.lib.cnf_model_last_path(self._h), "?")
+
+  def set_profiling(self, on: bool) -> None:
+    _capi.check(self.lib.cnf_model_set_profiling(self._h, 1 if on else 0), "cnf_model_set_profiling")
+
+  def read_profile(self):
+    """(flow kernel ms, table build ms, launches, samples) summed over the
+    profiled launches since the last read; waits for them."""
+    f, b = _capi.ctypes.c_double(), _capi.ctypes.c_double()
+    n, smp = _capi.ctypes.c_int64(), _capi.ctypes.c_int64()
+    _capi.check(self.lib.cnf_model_read_profile(self._h, _capi.ctypes.byref(f), _capi.ctypes.byref(b),
+                                                _capi.ctypes.byref(n), _capi.ctypes.byref(smp)),
+                "cnf_model_read_profile")
+    return f.value, b.value, n.value, smp.value
 
   def set_fast_math(self, on: bool) -> None:
     _capi.check(self.lib.cnf_model_set_fast_math(self._h, 1 if on else 0), "cnf_model_set_fast_math")
@@ -103,6 +150,12 @@ class FlowEngine:
     """Piecewise-linear conditioner tables (dim 2, slice-uniform condition):
     1 = for large launches (default), 2 = whenever they apply, 0 = never."""
     _capi.check(self.lib.cnf_model_set_pwl(self._h, int(mode)), "cnf_model_set_pwl")
+    self._pwl_mode = int(mode)
+
+  def set_precise(self, on: bool) -> None:
+    """cnf_model_set_precise: float64 position path of log_prob / inverse
+    (default on), or plain fp32."""
+    _capi.check(self.lib.cnf_model_set_precise(self._h, 1 if on else 0), "cnf_model_set_precise")
 
   def set_samples_per_lane(self, spl: int) -> None:
     """0: chosen by batch size (default); 1 / 2: force the one-sample or the
@@ -149,6 +202,8 @@ class FlowEngine:
     if pts.dtype == torch.float64:
       fn, name = getattr(self.lib, name + "_f64"), name + "_f64"
     c, c_block = self.cond(cond, B, pts.dtype)
+    if self._pwl_mode and c_block > 1 and B > 0 and pts.dtype == torch.float32:
+      self.reserve(-(-B // c_block))
     if out is not None:
       self._check_out(out, pts.shape, name + " out", pts.dtype)
     elif want_pts:
@@ -181,6 +236,8 @@ class FlowEngine:
     B = value.shape[0]
     f64 = value.dtype == torch.float64
     c, c_block = self.cond(cond, B, value.dtype)
+    if self._pwl_mode and c_block > 1 and B > 0 and not f64:
+      self.reserve(-(-B // c_block))
     lp = torch.empty(B, dtype=value.dtype, device=self.device)
     if B > 0:
       fn = self.lib.cnf_log_prob_f64 if f64 else self.lib.cnf_log_prob
@@ -209,6 +266,8 @@ class FlowEngine:
     if pts.shape[0] != need:
       raise ValueError(f"loss_terms: pts has {pts.shape[0]} rows, expected {need}")
     sums = torch.empty(n_slices, dtype=torch.float64, device=self.device)
+    if self._pwl_mode and n_slices > 0:
+      self.reserve(n_slices, _sets_of(spec))
     if n_slices > 0:
       with torch.cuda.device(self.device):
         _capi.check(self.lib.cnf_loss_terms(self._h, _capi.ctypes.byref(spec), pts.data_ptr(),
@@ -224,6 +283,8 @@ class FlowEngine:
       t = torch.as_tensor(np.asarray(t, dtype=np.float32))
     t = t.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
     sums = torch.empty(t.numel(), dtype=torch.float64, device=self.device)
+    if self._pwl_mode and t.numel() > 0:
+      self.reserve(t.numel(), _sets_of(spec))
     if t.numel() > 0:
       with torch.cuda.device(self.device):
         _capi.check(self.lib.cnf_loss_terms_seeded(self._h, _capi.ctypes.byref(spec), seed, off + first_sample,
@@ -327,6 +388,11 @@ class FlowEngine:
         _capi.check(self.lib.cnf_fill_normal(seed, (off + first_sample) * D, n_samples * D,
                                              out.data_ptr(), _stream_ptr(self.device)), "cnf_fill_normal")
     return out
+
+
+def _sets_of(spec) -> int:
+  """table sets per slice of a fused loss term: conditions t -+ dt/2 (and t)."""
+  return 2 if spec.kind == _capi.TERM_KINETIC else (3 if spec.kind <= _capi.TERM_FLOW_MATCHING else 1)
 
 
 def _num_samples(sample_shape) -> Tuple[int, Tuple[int, ...]]:

@@ -94,6 +94,8 @@ class Adam:
       _capi.check(lib.cnf_adam_step(params.flat.data_ptr(), grads.flat.data_ptr(), state.mu.data_ptr(),
                                     state.nu.data_ptr(), params.flat.numel(), self.lr, self.b1, self.b2, self.eps,
                                     state.step, _stream_ptr(dev)), "cnf_adam_step")
+    # the kernel wrote params.flat behind torch's back: engines must re-prepare (FlowEngine.load)
+    params.flat._cnf_epoch = getattr(params.flat, "_cnf_epoch", 0) + 1
     return state
 
 

@@ -14,14 +14,14 @@
  *    contiguous row-major float32 unless a parameter says otherwise;
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream);
  *    every compute entry point only enqueues work on that stream: no
- *    allocation, no synchronisation, graph-capturable.  One exception: large
- *    dim-2 flow calls with a slice-uniform condition build per-slice conditioner
- *    tables into a workspace kept per (model, stream); it is allocated by the
- *    first such call on a stream and re-allocated when a call has more slices
- *    than any before -- make one warm-up call before capturing a graph;
+ *    allocation, no synchronisation, graph-capturable.  Device memory is
+ *    allocated by cnf_model_create, cnf_model_reserve and cnf_grad_enable only;
  *  - return value: 0 on success, negative CNF_ERR_* otherwise; nothing throws;
  *  - a CnfModel may be used from several host threads as long as each uses its
- *    own stream and nobody calls cnf_model_set_params concurrently.
+ *    own stream and nobody calls cnf_model_set_params concurrently; a compute
+ *    call on another stream than the last cnf_model_set_params is ordered after
+ *    it (event wait), but set_params does not wait for compute calls still in
+ *    flight on OTHER streams -- finish those first.
  *
  * Condition argument (`c`, `c_block`): the condition of sample i is
  * c[i / c_block].  c_block == 1 is the per-sample form the reference uses for
@@ -70,8 +70,11 @@ void cnf_config_default(CnfConfig *cfg, int32_t dim);
 /* Number of float32 parameters of the flat layout below; < 0 on bad config.
  * 1 200 at dim=2, 11 824 at dim=10 (solvers.py:135-136 prints this count).
  *
- * Flat layout = haiku parameter tree in creation order (flows.py:46-86,
- * 146-158):  first[P]   then for l in 0..L-1, d in 1..D-1:
+ * Flat layout (this library's own order; it is NOT the order in which haiku
+ * creates the parameters -- hk's init traces log_prob, which visits layer L-1
+ * first (conditional.py:163-166) -- nor jax's key-sorted flattening: import a
+ * haiku tree BY NAME, INTEGRATION.md / cnf_ot_amd/params.py from_tree):
+ *   first[P]   then for l in 0..L-1, d in 1..D-1 (module names flows.py:46-86,146-158):
  *   mlp_layer{l}_d{d}/~/linear_0 w[(1+d)][H], b[H]; .../linear_{m} w[H][H],
  *   b[H] (m=1..M-1); linear_out_layer{l}_d{d} w[H][P], b[P];   P = 3K+1. */
 int64_t cnf_param_count(const CnfConfig *cfg);
@@ -90,6 +93,40 @@ void cnf_model_destroy(CnfModel *m);
  * on device) and snapshots the weights.  Must precede compute calls; call
  * again after every optimiser step. */
 int cnf_model_set_params(CnfModel *m, const float *params, void *stream);
+
+/* Workspace of the dim-2 table path (no reference counterpart: the reference
+ * re-evaluates the conditioner MLP per sample, flows.py:57-84).  Large dim-2
+ * calls whose condition is uniform over slices read the conditioner from exact
+ * piecewise-linear tables, one SET (num_layers tables, cnf_model_table_bytes()
+ * bytes) per time-slice and condition; the fused loss terms need up to three
+ * sets per slice (t - dt/2, t + dt/2, t).  cnf_model_reserve(m, stream, n_sets)
+ * makes room for n_sets sets for calls on `stream` (grows only; n_sets = 0
+ * releases it).  It allocates and may synchronise `stream`: call it outside
+ * graph capture.  Compute calls never allocate: a call with more slices than
+ * the reservation holds is processed in chunks, and without a (useful)
+ * reservation the same result comes from the MLP kernels.  2 048 sets cover the
+ * largest chunk a call is ever split into. */
+int cnf_model_reserve(CnfModel *m, void *stream, int64_t n_sets);
+int64_t cnf_model_reserved(CnfModel *m, void *stream);
+int64_t cnf_model_table_bytes(const CnfModel *m);
+
+/* Numerics of the data -> base direction (cnf_log_prob, cnf_inverse_logdet).
+ * log_prob = sum_d -x_d^2/2 + ildj multiplies the error of the recovered base
+ * point by |x| (up to 5), and an all-fp32 evaluation of the softmax-normalised
+ * knots leaves ~2e-6 in x: max |d log_prob| 1.1e-5 .. 1.5e-5 against a float64
+ * evaluation of the reference algorithm (conditional.py:316-321 in float64,
+ * solvers.py:23) on 65 536 samples.  on = 1 (the default): the softmax terms are
+ * evaluated to ~1e-9, and the knot prefix sums, the bin corner, the offset in
+ * the bin, the result and the base term are carried in float64 (the conditioner
+ * MLP, the slopes and the log-det terms stay fp32): max |d log_prob| ~2e-6, at
+ * ~1.5x the time of a data -> base call.  on = 0: plain fp32 throughout (what
+ * the fused loss terms use internally for their score differences). */
+int cnf_model_set_precise(CnfModel *m, int on);
+
+/* Which kernels the most recent compute call on this model ran: 1/2 = MLP flow
+ * kernel with one / two samples per lane, 3 = MFMA conditioner, 4 = conditioner
+ * tables, 5/6 = fused loss kernel on the MLP / on tables, 7 = float64. */
+int cnf_model_last_path(const CnfModel *m);
 
 /* Replaces: model.apply.forward(params, x, c) = flow.bijector.forward, and
  * flow.bijector.forward_and_log_det (flows.py:221-223, conditional.py:233-237,

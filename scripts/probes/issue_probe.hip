@@ -53,6 +53,43 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define P_ADD(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
 #define P_MULC(i) asm volatile("v_pk_mul_f32 %0, %0, %1 clamp" : "+v"(a[i]) : "v"(b));
 
+#define PROBE_DOUBLE(NAME, ASM)                                                        \
+  __global__ void NAME(float* out, int iters) {                                        \
+    double a[8];                                                                       \
+    for (int i = 0; i < 8; ++i) a[i] = 1.0 + 1e-3 * (threadIdx.x + i);                 \
+    const double b = 1.0000001, c = 1e-9;                                              \
+    for (int it = 0; it < iters; ++it) {                                               \
+      CHAIN8(ASM)                                                                      \
+    }                                                                                  \
+    double s = 0.;                                                                     \
+    for (int i = 0; i < 8; ++i) s += a[i];                                             \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)s;                             \
+  }
+#define D_FMA(i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+#define D_ADD(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+#define D_MUL(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define D_RCP(i) asm volatile("v_rcp_f64 %0, %0" : "+v"(a[i]));
+// conversions: a double chain element is narrowed and widened again (two instructions per step)
+#define D_CVT(i) { float t_; asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(t_) : "v"(a[i])); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a[i]) : "v"(t_)); }
+#define S_CVTU(i) { unsigned t_; asm volatile("v_cvt_u32_f32 %0, %1" : "=v"(t_) : "v"(a[i])); asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(a[i]) : "v"(t_)); }
+#define S_RNDNE(i) asm volatile("v_rndne_f32 %0, %0" : "+v"(a[i]));
+#define S_LDEXP(i) asm volatile("v_ldexp_f32 %0, %0, 1" : "+v"(a[i]));
+#define S_LSHLADD(i) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(c));
+#define S_FLOOR(i) asm volatile("v_floor_f32 %0, %0" : "+v"(a[i]));
+#define S_MIN(i) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define S_PKMOV(i) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(b));
+PROBE_DOUBLE(k_dfma, D_FMA)
+PROBE_DOUBLE(k_dadd, D_ADD)
+PROBE_DOUBLE(k_dmul, D_MUL)
+PROBE_DOUBLE(k_drcp, D_RCP)
+PROBE_DOUBLE(k_dcvt, D_CVT)
+PROBE_SCALAR(k_cvtu, S_CVTU)
+PROBE_SCALAR(k_rndne, S_RNDNE)
+PROBE_SCALAR(k_ldexp, S_LDEXP)
+PROBE_SCALAR(k_lshladd, S_LSHLADD)
+PROBE_SCALAR(k_floor, S_FLOOR)
+PROBE_SCALAR(k_min, S_MIN)
+PROBE_SCALAR(k_mov, S_PKMOV)
 PROBE_SCALAR(k_fma, S_FMA)
 PROBE_SCALAR(k_mul, S_MUL)
 PROBE_SCALAR(k_exp, S_EXP)
@@ -112,6 +149,10 @@ int main() {
     {"v_cmp_ge_f32_e64 + v_cndmask_e64", k_cmp_cnd},
     {"v_pk_fma_f32", k_pk_fma}, {"v_pk_mul_f32", k_pk_mul}, {"v_pk_add_f32", k_pk_add}, {"v_pk_mul_f32 clamp", k_pk_mul_clamp},
     {"v_exp_f32", k_exp}, {"v_log_f32", k_log}, {"v_rcp_f32", k_rcp}, {"v_sqrt_f32", k_sqrt},
+    {"v_fma_f64", k_dfma}, {"v_add_f64", k_dadd}, {"v_mul_f64", k_dmul}, {"v_rcp_f64", k_drcp},
+    {"v_cvt_f32_f64 + v_cvt_f64_f32", k_dcvt}, {"v_cvt_u32_f32 + v_cvt_f32_u32", k_cvtu},
+    {"v_rndne_f32", k_rndne}, {"v_floor_f32", k_floor}, {"v_ldexp_f32", k_ldexp}, {"v_lshl_add_u32", k_lshladd},
+    {"v_min_f32", k_min}, {"v_mov_b32", k_mov},
   };
   printf("%d CUs, nominal clock %.0f MHz; cycles per wave64 instruction per SIMD (at the nominal clock)\n", num_cus, clock_hz / 1e6);
   for (int w : {1, 2, 4}) {
