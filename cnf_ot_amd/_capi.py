@@ -89,7 +89,7 @@ _INTERNAL = {
   "cnf_model_read_profile": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
 }
-PATH_NAMES = {0: "none", 1: "mlp1", 2: "mlp2", 3: "mfma", 4: "tables", 5: "loss_mlp", 6: "loss_tables", 7: "f64"}
+PATH_NAMES = {0: "none", 1: "mlp1", 2: "mlp2", 3: "mfma", 4: "tables", 5: "loss_mlp", 6: "loss_tables", 7: "f64", 8: "detect"}
 
 _lib = None
 

@@ -83,7 +83,7 @@ struct CnfModel {
   int use_pwl;            // 1: piecewise-linear conditioner tables at dim 2 (cnf_pwl.h)
   // table workspaces [sets][L][PWL_TBL], one per stream (calls on different streams never share one).
   // Allocated ONLY by cnf_model_reserve; the compute entry points look theirs up and never allocate.
-  struct PwlWorkspace { float* tables; int64_t sets; };
+  struct PwlWorkspace { float* tables; int64_t sets; uint32_t epoch; };
   std::mutex pwl_mu;
   std::unordered_map<void*, PwlWorkspace> pwl_ws;
   // cnf_model_set_params records `prep_event` after its kernel; a compute call on another stream waits for it
@@ -106,6 +106,7 @@ enum CnfPath {
   CNF_PATH_LOSS_MLP = 5,    // loss_kernel
   CNF_PATH_LOSS_TABLES = 6, // pwl_build_kernel + loss_pwl_kernel
   CNF_PATH_F64 = 7,         // float64 instantiation
+  CNF_PATH_DETECT = 8,      // per-sample condition: uniformity check + table kernels + MLP kernel, gated on the device
 };
 
 #ifdef CNF_MINIMAL_CONFIGS   /* faster builds while iterating on the kernels */

@@ -39,6 +39,11 @@ template <class R> struct FlowArgsT {
   int64_t c_block;
   int32_t c_mode, aux_mode;
   int32_t div_magic;     // ceil(2^32 / D): e / D == umulhi(e, magic) for e < 2^16
+  // device-side choice between two kernels enqueued for the same call (uniform-condition detection,
+  // cond_uniform_kernel): this kernel runs only if (*gate == gate_epoch) == gate_want; null: always
+  const uint32_t* gate;
+  uint32_t gate_epoch;
+  int32_t gate_want;
 };
 typedef FlowArgsT<float> FlowArgs;
 typedef FlowArgsT<double> FlowArgsD;
@@ -294,6 +299,7 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
   R* tab = lds;
   R* U = lds + HDR;
   R* O = U + a.m.D * TS;
+  if (gate_closed(a)) return;
   for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = table_of<R>(a.m)[i];
   double* e2tab = nullptr;
   if constexpr (PRECISE) {                 // [.. U O][2^(-i/32) table]; HDR and D * TS are even: 8-byte aligned
@@ -349,7 +355,26 @@ struct PwlArgs {
   const float* tables;
   int64_t B, slice_len;
   int32_t n_slices, tiles_per_slice, aux_mode;
+  const uint32_t* gate;      // see FlowArgsT
+  uint32_t gate_epoch;
+  int32_t gate_want;
 };
+
+// Every reference call site hands the flow one time broadcast to cond[B,1] (applications.py:153,226,231):
+// per-sample in form, uniform in content.  For launches large enough for the table path this kernel checks it on
+// the device: a block that finds c[i] != c[0] stamps the call's epoch into *flag.  The table kernels and the MLP
+// kernel of the call are both enqueued and read the stamp: exactly one of them does the work (no host round trip).
+__global__ void cond_uniform_kernel(const float* __restrict__ c, int64_t B, uint32_t* flag, uint32_t epoch) {
+  const uint32_t c0 = __float_as_uint(c[0]);
+  bool diff = false;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x)
+    diff |= __float_as_uint(c[i]) != c0;
+  if (__syncthreads_or(diff) && threadIdx.x == 0) *flag = epoch;
+}
+
+template <class A> __device__ __forceinline__ bool gate_closed(const A& a) {
+  return a.gate && ((*a.gate == a.gate_epoch) ? 1 : 0) != a.gate_want;
+}
 
 // Stage the L tables of (set, slice) into LDS: header arrays + the rows in use, at most PWL_LROWS.
 __device__ __forceinline__ void pwl_stage(float* tbl, const float* __restrict__ g0, int L, int tid, int nthreads) {
@@ -406,6 +431,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
   float* tbl = lds_raw + HDR;
   const int tid = threadIdx.x;
   const int L = a.m.L;
+  if (gate_closed(a)) return;
   for (int i = tid; i < hdr_floats(K); i += PWL_THREADS) tab[i] = table_of<float>(a.m)[i];
   const SplineConsts& sc = sc_of<float>(a.m);
   double* e2tab = nullptr;
@@ -1078,7 +1104,7 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
   const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * ts) * sizeof(float) +
                      (precise ? sizeof(double) * cnf::EXP2_N : 0);
   if (m->fast_math && m->use_mfma && m->mfma_off > 0 && m->cfg.hidden_size == 16 && m->cfg.num_bins == 5) {
-    m->last_path = CNF_PATH_MFMA;
+    if (!a.gate) m->last_path = CNF_PATH_MFMA;
     ProfScope ps(m, stream, false, a.B, CNF_PATH_MFMA);
     if (precise) {
       if (spl == 2) CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, v2f, true, PR>), grid, lds, stream, a);
@@ -1090,8 +1116,8 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
     ps.done();
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
   }
-  m->last_path = spl == 2 ? CNF_PATH_MLP2 : CNF_PATH_MLP1;
-  ProfScope ps(m, stream, false, a.B, m->last_path);
+  if (!a.gate) m->last_path = spl == 2 ? CNF_PATH_MLP2 : CNF_PATH_MLP1;
+  ProfScope ps(m, stream, false, a.B, spl == 2 ? CNF_PATH_MLP2 : CNF_PATH_MLP1);
 #define X(HH, KK)                                                                             \
   if (m->cfg.hidden_size == HH && m->cfg.num_bins == KK) {                                    \
     if (precise) {                                                                            \
@@ -1113,11 +1139,15 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
 
 // This stream's table workspace (cnf_model_reserve).  Lookup only: the compute entry points never allocate,
 // free or synchronise.  *sets = 0 when the stream has no reservation.
-static void pwl_workspace(CnfModel* m, hipStream_t stream, float** tables, int64_t* sets) {
+static void pwl_workspace(CnfModel* m, hipStream_t stream, float** tables, int64_t* sets, uint32_t** flag = nullptr,
+                          uint32_t* epoch = nullptr) {
   std::lock_guard<std::mutex> lock(m->pwl_mu);
   auto it = m->pwl_ws.find((void*)stream);
   if (it == m->pwl_ws.end()) { *tables = nullptr; *sets = 0; return; }
   *tables = it->second.tables; *sets = it->second.sets;
+  // the uniform-condition stamp lives behind the tables; a call that uses it takes a fresh epoch
+  if (flag) { *flag = reinterpret_cast<uint32_t*>(it->second.tables + it->second.sets * m->cfg.num_layers * (int64_t)cnf::PWL_TBL);
+              *epoch = ++it->second.epoch; }
 }
 
 extern "C" int64_t cnf_model_table_bytes(const CnfModel* m) {
@@ -1135,11 +1165,16 @@ extern "C" int cnf_model_reserve(CnfModel* m, void* stream, int64_t n_sets) {
     ws.tables = nullptr; ws.sets = 0;
   }
   if (n_sets == 0) { m->pwl_ws.erase(stream); return CNF_OK; }
-  if (hipMalloc((void**)&ws.tables, (size_t)cnf_model_table_bytes(m) * (size_t)n_sets) != hipSuccess) {
+  if (hipMalloc((void**)&ws.tables, (size_t)cnf_model_table_bytes(m) * (size_t)n_sets + 64) != hipSuccess) {
     m->pwl_ws.erase(stream);
     return CNF_ERR_NOMEM;
   }
-  ws.sets = n_sets;
+  // the stamp of cond_uniform_kernel starts at 0; epochs count from 1
+  if (hipMemset(reinterpret_cast<char*>(ws.tables) + (size_t)cnf_model_table_bytes(m) * (size_t)n_sets, 0, 64) != hipSuccess) {
+    (void)hipFree(ws.tables); m->pwl_ws.erase(stream);
+    return CNF_ERR_HIP;
+  }
+  ws.sets = n_sets; ws.epoch = 0;
   return CNF_OK;
 }
 
@@ -1161,8 +1196,12 @@ static bool pwl_config_ok(const CnfModel* m) {
 // The piecewise-linear path (cnf_pwl.h): dim 2, H = 16, K = 5, two MLP layers, a condition that is
 // uniform over slices of even length, 16-byte aligned points.  Returns CNF_ERR_UNSUPPORTED when the
 // launch does not qualify (the caller then runs the MLP kernel).
+// `detect`: the condition is per-sample in form (c_block == 1); the caller passes c_block = B here.  The
+// uniformity check is enqueued first and the table kernels run only if it finds c uniform; *gate / *gate_epoch
+// return the stamp for the MLP kernel the caller enqueues behind them (which runs only if c is NOT uniform).
 static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float* c, int64_t c_block,
-                        float* out, float* aux, int aux_mode, int64_t B, hipStream_t stream) {
+                        float* out, float* aux, int aux_mode, int64_t B, hipStream_t stream,
+                        bool detect = false, const uint32_t** gate = nullptr, uint32_t* gate_epoch = nullptr) {
   if (!pwl_config_ok(m)) return CNF_ERR_UNSUPPORTED;
   const int L = m->cfg.num_layers;
   const bool precise = to_base && m->precise;
@@ -1205,8 +1244,18 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
     if (chunk < 1) return CNF_ERR_UNSUPPORTED;
     if (m->use_pwl == 1 && chunk < n_slices && chunk * tps < (int64_t)m->num_cus) return CNF_ERR_UNSUPPORTED;
   }
+  uint32_t* flag = nullptr;
+  uint32_t epoch = 0;
+  if (detect) {
+    int64_t sets = 0;
+    pwl_workspace(m, stream, &tables, &sets, &flag, &epoch);
+    int64_t g = (B + 4095) / 4096;
+    if (g > 4 * (int64_t)m->num_cus) g = 4 * (int64_t)m->num_cus;
+    hipLaunchKernelGGL(cnf::cond_uniform_kernel, dim3((unsigned)g), dim3(256), 0, stream, c, B, flag, epoch);
+    *gate = flag; *gate_epoch = epoch;
+  }
   const double sp_offset = log(exp(1.0 - (double)m->cfg.min_knot_slope) - 1.0);
-  m->last_path = CNF_PATH_TABLES;
+  m->last_path = detect ? CNF_PATH_DETECT : CNF_PATH_TABLES;
   for (int64_t s0 = 0; s0 < n_slices; s0 += chunk) {
     const int64_t ns = n_slices - s0 < chunk ? n_slices - s0 : chunk;
     const int64_t first = s0 * slice_len;
@@ -1221,6 +1270,7 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
     a.B = (B - first) < ns * slice_len ? (B - first) : ns * slice_len;
     a.slice_len = slice_len;
     a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps; a.aux_mode = aux_mode;
+    a.gate = flag; a.gate_epoch = epoch; a.gate_want = 0;        // tables: only if no block stamped a difference
     const int64_t tiles = ns * tps;
     const int64_t grid = tiles < m->num_cus ? tiles : m->num_cus;
     if (precise)
@@ -1241,7 +1291,15 @@ static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, 
   if (!m->params_set) return CNF_ERR_INVALID;
   if (B == 0) return CNF_OK;
   if (wait_for_params(m, (hipStream_t)stream) != CNF_OK) return CNF_ERR_HIP;
-  {
+  const uint32_t* gate = nullptr;
+  uint32_t gate_epoch = 0;
+  if (c_block == 1 && B > 1) {
+    // per-sample conditions: uniform in every reference call (one time broadcast to cond[B,1]).  When the launch
+    // is one the table path would take as a single slice, enqueue the check + the table kernels + (below) the MLP
+    // kernel, gated on the device by the check's result.
+    const int r = run_flow_pwl(m, to_base, in, c, B, out, aux, aux_mode, B, (hipStream_t)stream, true, &gate, &gate_epoch);
+    if (r != CNF_OK && r != CNF_ERR_UNSUPPORTED) return r;
+  } else {
     const int r = run_flow_pwl(m, to_base, in, c, c_block, out, aux, aux_mode, B, (hipStream_t)stream);
     if (r != CNF_ERR_UNSUPPORTED) return r;
   }
@@ -1249,6 +1307,7 @@ static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, 
   a.m = model_args(m);
   a.in = in; a.c = c; a.out = out; a.aux = aux;
   a.B = B; a.c_block = c_block;
+  a.gate = gate; a.gate_epoch = gate_epoch; a.gate_want = 1;     // MLP kernel: only if a difference was stamped
   a.aux_mode = aux_mode;
   a.div_magic = m->div_magic;
   int spl = m->fast_math ? samples_per_lane(m, B) : 1;
@@ -1452,6 +1511,7 @@ static int run_flow_f64(CnfModel* m, bool to_base, const double* in, const doubl
   a.m = model_args(m);
   a.in = in; a.c = c; a.out = out; a.aux = aux;
   a.B = B; a.c_block = c_block; a.aux_mode = aux_mode; a.div_magic = m->div_magic;
+  a.gate = nullptr; a.gate_epoch = 0; a.gate_want = 0;
   if (c_block >= B) a.c_mode = C_SINGLE;
   else if (c_block == 1) a.c_mode = C_PER_SAMPLE;
   else if (c_block % TILE == 0) a.c_mode = C_TILE_UNIFORM;

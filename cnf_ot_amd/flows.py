@@ -202,8 +202,8 @@ class FlowEngine:
     if pts.dtype == torch.float64:
       fn, name = getattr(self.lib, name + "_f64"), name + "_f64"
     c, c_block = self.cond(cond, B, pts.dtype)
-    if self._pwl_mode and c_block > 1 and B > 0 and pts.dtype == torch.float32:
-      self.reserve(-(-B // c_block))
+    if self._pwl_mode and B > 0 and pts.dtype == torch.float32:
+      self.reserve(-(-B // c_block) if c_block > 1 else 1)      # per-sample cond: one set, if it proves uniform
     if out is not None:
       self._check_out(out, pts.shape, name + " out", pts.dtype)
     elif want_pts:
@@ -236,8 +236,8 @@ class FlowEngine:
     B = value.shape[0]
     f64 = value.dtype == torch.float64
     c, c_block = self.cond(cond, B, value.dtype)
-    if self._pwl_mode and c_block > 1 and B > 0 and not f64:
-      self.reserve(-(-B // c_block))
+    if self._pwl_mode and B > 0 and not f64:
+      self.reserve(-(-B // c_block) if c_block > 1 else 1)
     lp = torch.empty(B, dtype=value.dtype, device=self.device)
     if B > 0:
       fn = self.lib.cnf_log_prob_f64 if f64 else self.lib.cnf_log_prob

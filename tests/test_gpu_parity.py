@@ -401,6 +401,43 @@ def test_compute_calls_never_allocate(dev):
   eng.set_pwl(1)
 
 
+def test_per_sample_uniform_condition_is_detected_on_device(dev):
+  """The reference's literal call form: one time broadcast to cond[B,1]
+  (applications.py:153,226,231) is per-sample in form and uniform in content.
+  For a launch large enough for the table path the library checks uniformity
+  on the device and runs the table kernels, with the MLP kernel enqueued behind
+  them as the gated alternative: a uniform cond[B,1] gives the scalar-condition
+  table result bit for bit, a cond[B,1] with one different entry gives the MLP
+  kernel's per-sample result bit for bit -- no host synchronisation either way."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  cfg = FlowConfig(dim=2)
+  eng = FlowEngine(cfg, dev).load(Params.random(cfg, 0.2, seed=12, device=dev))
+  B = 1 << 21
+  x = eng.normal(5, B)
+  for fn in ("sample_logprob", "log_prob"):
+    call = (lambda c: eng.sample_logprob(x, c)) if fn == "sample_logprob" else (lambda c: (eng.log_prob(x, c),))
+    ref_tab = call(torch.tensor([0.3], device=dev))
+    assert eng.last_path() == "tables"
+    c_uni = torch.full((B, 1), 0.3, device=dev)
+    got = call(c_uni)
+    assert eng.last_path() == "detect"
+    for a, b in zip(got, ref_tab):
+      assert torch.equal(a, b), fn
+    c_mix = c_uni.clone()
+    c_mix[B - 7, 0] = 0.31
+    got = call(c_mix)
+    assert eng.last_path() == "detect"
+    eng.set_pwl(0)
+    ref_mlp = call(c_mix)
+    assert eng.last_path() in ("mlp1", "mlp2")
+    eng.set_pwl(1)
+    for a, b in zip(got, ref_mlp):
+      assert torch.equal(a, b), fn
+  # a single 65 536-sample batch stays on the MLP kernel (the tables do not pay there): no check is enqueued
+  eng.sample_logprob(x[:65536], c_uni[:65536])
+  assert eng.last_path() in ("mlp1", "mlp2")
+
+
 def test_table_path_many_slices(dev):
   """More slices than one build + flow kernel pair takes (2 048): the call is
   processed in chunks against a bounded workspace; same numbers as the MLP
