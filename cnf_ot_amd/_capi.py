@@ -85,11 +85,12 @@ _INTERNAL = {
   "cnf_model_set_samples_per_lane": (ctypes.c_int, [_P, ctypes.c_int]),
   "cnf_model_set_mfma": (ctypes.c_int, [_P, ctypes.c_int]),
   "cnf_model_set_pwl": (ctypes.c_int, [_P, ctypes.c_int]),
+  "cnf_model_set_dpar": (ctypes.c_int, [_P, ctypes.c_int]),
   "cnf_model_set_profiling": (ctypes.c_int, [_P, ctypes.c_int]),
   "cnf_model_read_profile": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
 }
-PATH_NAMES = {0: "none", 1: "mlp1", 2: "mlp2", 3: "mfma", 4: "tables", 5: "loss_mlp", 6: "loss_tables", 7: "f64", 8: "detect"}
+PATH_NAMES = {0: "none", 1: "mlp1", 2: "mlp2", 3: "mfma", 4: "tables", 5: "loss_mlp", 6: "loss_tables", 7: "f64", 8: "detect", 9: "dpar"}
 
 _lib = None
 

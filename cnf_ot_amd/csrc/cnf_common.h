@@ -81,6 +81,7 @@ struct CnfModel {
   float* grad_slabs;      // per-wave gradient slabs (cnf_grad_enable), or null
   int64_t grad_max_blocks;
   int use_pwl;            // 1: piecewise-linear conditioner tables at dim 2 (cnf_pwl.h)
+  int use_dpar;           // 1: wave-per-dimension kernel for small base -> data launches at dim >= 3
   // table workspaces [sets][L][PWL_TBL], one per stream (calls on different streams never share one).
   // Allocated ONLY by cnf_model_reserve; the compute entry points look theirs up and never allocate.
   struct PwlWorkspace { float* tables; int64_t sets; uint32_t epoch; };
@@ -106,6 +107,7 @@ enum CnfPath {
   CNF_PATH_LOSS_MLP = 5,    // loss_kernel
   CNF_PATH_LOSS_TABLES = 6, // pwl_build_kernel + loss_pwl_kernel
   CNF_PATH_F64 = 7,         // float64 instantiation
+  CNF_PATH_DPAR = 9,        // flow_dpar_kernel: one wave per conditioned dimension (dim >= 3, base -> data)
   CNF_PATH_DETECT = 8,      // per-sample condition: uniformity check + table kernels + MLP kernel, gated on the device
 };
 

@@ -64,8 +64,6 @@ enum TabField {
   F_XK,      // x knots [K+1]
   F_YK,      // y knots [K+1]
   F_TAIL,    // d_lo, d_hi, log d_lo, log d_hi, 1/d_lo, 1/d_hi
-  F_X0L,     // float64 knot - (float)knot of F_X0 / F_Y0: the precise position path carries the bin's
-  F_Y0L,     // corner as a float pair
   F_COUNT
 };
 enum { T_DLO = 0, T_DHI, T_LOG_DLO, T_LOG_DHI, T_INV_DLO, T_INV_DHI };
@@ -326,36 +324,17 @@ template <> struct BinRow<v2f> {
   template <int K> __device__ __forceinline__ v2f get(int f) const { return v2f{px[tab_off(f, K)], py[tab_off(f, K)]}; }
 };
 
-// PRECISE (forward direction only): the bin corner (x0, y0) is a float pair hi + lo rounded from the float64
-// table, the offset inside the bin is (v - x0_hi) - x0_lo and the result y0_hi + (y0_lo + increment); `out_lo`
-// receives what rounding `out` to fp32 dropped (for the base term -x^2/2 of log_prob).
-template <int K, bool INV, bool FAST, class T, bool PRECISE = false>
+template <int K, bool INV, bool FAST, class T>
 __device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab, T v,
-                                             const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld,
-                                             T& out_lo) {
+                                             const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld) {
   typedef typename Lanes<T>::real R;
   const R* pos = tab + tab_off(INV ? F_YK : F_XK, K);
   const typename Lanes<T>::index k = bin_of<K>(pos, v);
   const BinRow<T> row(tab, k);
-  if constexpr (PRECISE && !INV) {
-    using M = Math<FAST>;
-    const T x0 = row.template get<K>(F_X0), y0 = row.template get<K>(F_Y0), bh = row.template get<K>(F_BH);
-    const T s = row.template get<K>(F_S), st = row.template get<K>(F_ST);
-    const T d0 = row.template get<K>(F_D0), d1 = row.template get<K>(F_D1);
-    const T z = clip01(((v - x0) - row.template get<K>(F_X0L)) * row.template get<K>(F_IBW));
-    const T sq_z = z * z, z1mz = z - sq_z, omz = 1.0f - z;
-    const T iden = M::rcp(vfma(st, z1mz, s));
-    const T inc = vfma(bh * vfma(s, sq_z, d0 * z1mz), iden, row.template get<K>(F_Y0L));
-    out = y0 + inc;
-    out_lo = inc - (out - y0);        // fast two-sum: |y0| >= |inc| except next to y0 = 0, where both are tiny
-    const T num2 = vfma(d1, sq_z, vfma(s * 2.0f, z1mz, d0 * omz * omz));
-    ld = row.template get<K>(F_L2S) + M::log(num2 * iden * iden);
-  } else {
-    rqs_bin_eval<INV, FAST, T>(v, row.template get<K>(F_X0), row.template get<K>(F_Y0), row.template get<K>(F_BW),
-                               row.template get<K>(F_BH), row.template get<K>(F_IBW),
-                               row.template get<K>(F_S), row.template get<K>(F_ST), row.template get<K>(F_D0),
-                               row.template get<K>(F_D1), row.template get<K>(F_L2S), out, ld);
-  }
+  rqs_bin_eval<INV, FAST, T>(v, row.template get<K>(F_X0), row.template get<K>(F_Y0), row.template get<K>(F_BW),
+                             row.template get<K>(F_BH), row.template get<K>(F_IBW),
+                             row.template get<K>(F_S), row.template get<K>(F_ST), row.template get<K>(F_D0),
+                             row.template get<K>(F_D1), row.template get<K>(F_L2S), out, ld);
   if (maybe_outside(v, sc.lo, sc.hi)) {   // linear tails (rare: |v| >= 10)
     const auto below = vle(v, sc.lo);
     const auto above = vge(v, sc.hi);
@@ -368,14 +347,7 @@ __device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab,
     ld = vsel(below, splat<T>(INV ? -tl[T_LOG_DLO] : tl[T_LOG_DLO]), ld);
     out = vsel(above, hi_out, out);
     ld = vsel(above, splat<T>(INV ? -tl[T_LOG_DHI] : tl[T_LOG_DHI]), ld);
-    if constexpr (PRECISE) out_lo = vsel(below, splat<T>(0.0f), vsel(above, splat<T>(0.0f), out_lo));
   }
-}
-template <int K, bool INV, bool FAST, class T>
-__device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab, T v,
-                                             const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld) {
-  T unused;
-  table_spline<K, INV, FAST, T, false>(tab, v, sc, out, ld, unused);
 }
 
 // ---------------------------------------------------------------------------
@@ -574,18 +546,47 @@ template <> struct BaseAcc<double> {       // (the float64 kernels never take th
   __device__ __forceinline__ double log_prob(double ildj, int) const { return ildj; }
 };
 
+// 1 / x in float64: hardware fp32 reciprocal + one Newton step (v_rcp_f64 issues at a quarter of the rate)
+template <bool FAST> __device__ __forceinline__ double rcp_f64(double x) {
+  const double r = (double)Math<FAST>::rcp((float)x);
+  return r * fma(-x, r, 2.0);
+}
+
+// The forward rational-quadratic map inside one bin in float64, from the bin's corner (x0, y0), width, height and
+// the two fp32 slopes; `v + v_lo` is the input as a float pair.  Returns the result as a float pair and log f'.
+template <bool FAST>
+__device__ __forceinline__ void rqs_fwd_bin_f64(float v, float v_lo, double x0, double y0, double bw, double bh,
+                                                float d0, float d1, float& out, float& out_lo, float& ld) {
+  using M = Math<FAST>;
+  const double ibw = rcp_f64<FAST>(bw);
+  const double s = bh * ibw;
+  const double z = fmin(fmax((((double)v + (double)v_lo) - x0) * ibw, 0.0), 1.0);
+  const double zz = z * z, z1mz = z - zz;
+  const double st = ((double)d1 + (double)d0) - 2.0 * s;
+  const double den = fma(st, z1mz, s);
+  const double iden = rcp_f64<FAST>(den);
+  const double out_d = fma(bh * fma(s, zz, (double)d0 * z1mz), iden, y0);
+  out = (float)out_d;
+  out_lo = (float)(out_d - (double)out);
+  // log f' = 2 log s + log(d1 z^2 + 2 s z (1 - z) + d0 (1 - z)^2) - 2 log den: relative accuracy is enough
+  const float zf = (float)z, sf = (float)s, omz = 1.0f - zf, z1f = (float)z1mz;
+  const float num2 = fmaf(d1, zf * zf, fmaf(2.0f * sf, z1f, d0 * omz * omz));
+  const float q = sf * (float)iden;
+  ld = M::log(num2 * q * q);
+}
+
 // LOG2_UNITS: the 2K softmax logits are already in log2 units and the slope logits carry the softplus offset
-// (rows of the conditioner tables, cnf_pwl.h).  Returns out (fp32) and what its rounding dropped (`out_lo`).
+// (rows of the conditioner tables, cnf_pwl.h).  The input is the float pair v + v_lo (what the previous layer's
+// rounding dropped); returns out (fp32) and what ITS rounding dropped (`out_lo`).
 template <int K, bool FAST, bool LOG2_UNITS>
-__device__ __forceinline__ void cond_spline_precise(const float (&th)[3 * K + 1], float v, const SplineConsts& sc,
-                                                    const PreciseConsts& pc, const double* e2tab,
-                                                    float& out, float& ld, float& out_lo) {
+__device__ __forceinline__ void cond_spline_precise(const float (&th)[3 * K + 1], float v, float v_lo,
+                                                    const SplineConsts& sc, const PreciseConsts& pc,
+                                                    const double* e2tab, float& out, float& ld, float& out_lo) {
   using M = Math<FAST>;
   float mw = th[0], mh = th[K];
 #pragma unroll
   for (int k = 1; k < K; ++k) { mw = fmaxf(mw, th[k]); mh = fmaxf(mh, th[K + k]); }
-  double Sw[K + 1], Sh[K + 1];
-  float ew[K], eh[K];
+  double Sw[K + 1], Sh[K + 1], ew[K], eh[K];
   Sw[0] = 0.0; Sh[0] = 0.0;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -595,22 +596,18 @@ __device__ __forceinline__ void cond_spline_precise(const float (&th)[3 * K + 1]
       tw = dw * LOG2E; twe = fmaf(dw, LOG2E, -tw) + dw * LOG2E_LO;
       tg = dh * LOG2E; tge = fmaf(dh, LOG2E, -tg) + dh * LOG2E_LO;
     }
-    const double e_w = exp2_precise(tw, twe, e2tab), e_h = exp2_precise(tg, tge, e2tab);
-    ew[k] = (float)e_w; eh[k] = (float)e_h;
-    Sw[k + 1] = Sw[k] + e_w; Sh[k + 1] = Sh[k] + e_h;
+    ew[k] = exp2_precise(tw, twe, e2tab); eh[k] = exp2_precise(tg, tge, e2tab);
+    Sw[k + 1] = Sw[k] + ew[k]; Sh[k + 1] = Sh[k] + eh[k];
   }
-  // 1 / E: fp32 reciprocal, one Newton step in float64
-  double rw = (double)M::rcp((float)Sw[K]), rh = (double)M::rcp((float)Sh[K]);
-  rw = rw * fma(-Sw[K], rw, 2.0);
-  rh = rh * fma(-Sh[K], rh, 2.0);
-  const float aw = (float)rw * sc.span_eff, ah = (float)rh * sc.span_eff;
+  const double aw = pc.span_eff * rcp_f64<FAST>(Sw[K]), ah = pc.span_eff * rcp_f64<FAST>(Sh[K]);
   // bin on the fp32-rounded x knots; the selected bin's prefix sums, terms and slope logits by select chains
-  double Sw_sel = 0.0, Sh_sel = 0.0;
-  float ew_sel = ew[0], eh_sel = eh[0], t0 = th[2 * K], t1 = th[2 * K + 1];
+  const float awf = (float)aw;
+  double Sw_sel = 0.0, Sh_sel = 0.0, ew_sel = ew[0], eh_sel = eh[0];
+  float t0 = th[2 * K], t1 = th[2 * K + 1];
   int kk = 0;
 #pragma unroll
   for (int j = 1; j < K; ++j) {
-    const float knot = fmaf((float)Sw[j], aw, sc.lo + (float)j * sc.min_bin);
+    const float knot = fmaf((float)Sw[j], awf, sc.lo + (float)j * sc.min_bin);
     const bool ge = v >= knot;
     Sw_sel = ge ? Sw[j] : Sw_sel; Sh_sel = ge ? Sh[j] : Sh_sel;
     ew_sel = ge ? ew[j] : ew_sel; eh_sel = ge ? eh[j] : eh_sel;
@@ -618,21 +615,10 @@ __device__ __forceinline__ void cond_spline_precise(const float (&th)[3 * K + 1]
     kk += ge ? 1 : 0;
   }
   const double base_k = fma((double)kk, pc.min_bin, pc.lo);
-  const double x0 = fma(pc.span_eff, Sw_sel * rw, base_k), y0 = fma(pc.span_eff, Sh_sel * rh, base_k);
-  const float bw = fmaf(ew_sel, aw, sc.min_bin), bh = fmaf(eh_sel, ah, sc.min_bin);
+  const double x0 = fma(aw, Sw_sel, base_k), y0 = fma(ah, Sh_sel, base_k);
+  const double bw = fma(aw, ew_sel, pc.min_bin), bh = fma(ah, eh_sel, pc.min_bin);
   const float d0 = knot_slope<FAST, float, LOG2_UNITS>(t0, sc), d1 = knot_slope<FAST, float, LOG2_UNITS>(t1, sc);
-  const float ibw = M::rcp(bw);
-  const float s = bh * ibw, st = d1 + d0 - 2.0f * s;
-  const float z = clip01((float)((double)v - x0) * ibw);
-  const float sq_z = z * z, z1mz = z - sq_z, omz = 1.0f - z;
-  const float iden = M::rcp(fmaf(st, z1mz, s));
-  const float inc = bh * fmaf(s, sq_z, d0 * z1mz) * iden;
-  const double out_d = y0 + (double)inc;
-  out = (float)out_d;
-  out_lo = (float)(out_d - (double)out);
-  const float num2 = fmaf(d1, sq_z, fmaf(2.0f * s, z1mz, d0 * omz * omz));
-  const float q = s * iden;
-  ld = M::log(num2 * q * q);
+  rqs_fwd_bin_f64<FAST>(v, v_lo, x0, y0, bw, bh, d0, d1, out, out_lo, ld);
   if (maybe_outside(v, sc.lo, sc.hi)) {      // linear tails: bin 0 / bin K-1 were selected
     if (v <= sc.lo) { out = fmaf(v - sc.lo, d0, sc.lo); ld = M::log(d0); out_lo = 0.0f; }
     if (v >= sc.hi) { out = fmaf(v - sc.hi, d1, sc.hi); ld = M::log(d1); out_lo = 0.0f; }
@@ -640,15 +626,39 @@ __device__ __forceinline__ void cond_spline_precise(const float (&th)[3 * K + 1]
 }
 
 template <int K, bool FAST, bool LOG2_UNITS>
-__device__ __forceinline__ void cond_spline_precise(const v2f (&th)[3 * K + 1], v2f v, const SplineConsts& sc,
+__device__ __forceinline__ void cond_spline_precise(const v2f (&th)[3 * K + 1], v2f v, v2f v_lo, const SplineConsts& sc,
                                                     const PreciseConsts& pc, const double* e2tab,
                                                     v2f& out, v2f& ld, v2f& out_lo) {
   float tx[3 * K + 1], ty[3 * K + 1];
 #pragma unroll
   for (int j = 0; j < 3 * K + 1; ++j) { tx[j] = th[j].x; ty[j] = th[j].y; }
   float ox, lx, rx, oy, ly, ry;
-  cond_spline_precise<K, FAST, LOG2_UNITS>(tx, v.x, sc, pc, e2tab, ox, lx, rx);
-  cond_spline_precise<K, FAST, LOG2_UNITS>(ty, v.y, sc, pc, e2tab, oy, ly, ry);
+  cond_spline_precise<K, FAST, LOG2_UNITS>(tx, v.x, v_lo.x, sc, pc, e2tab, ox, lx, rx);
+  cond_spline_precise<K, FAST, LOG2_UNITS>(ty, v.y, v_lo.y, sc, pc, e2tab, oy, ly, ry);
+  out = v2f{ox, oy}; ld = v2f{lx, ly}; out_lo = v2f{rx, ry};
+}
+
+// The shared `first` spline on the precise path: bin from the fp32 knots, the bin's constants from the float64
+// copy of the prepared table (`tabd`, staged in LDS), the in-bin map in float64.
+template <int K, bool FAST>
+__device__ __forceinline__ void table_spline_precise(const float* tab, const double* tabd, float v, float v_lo,
+                                                     const SplineConsts& sc, float& out, float& ld, float& out_lo) {
+  const int k = bin_of<K, float>(tab + tab_off(F_XK, K), v);
+  const double* r = tabd + k;
+  rqs_fwd_bin_f64<FAST>(v, v_lo, r[tab_off(F_X0, K)], r[tab_off(F_Y0, K)], r[tab_off(F_BW, K)], r[tab_off(F_BH, K)],
+                        (float)r[tab_off(F_D0, K)], (float)r[tab_off(F_D1, K)], out, out_lo, ld);
+  if (maybe_outside(v, sc.lo, sc.hi)) {
+    const float* tl = tab + tab_off(F_TAIL, K);
+    if (v <= sc.lo) { out = fmaf(v - sc.lo, tl[T_DLO], sc.lo); ld = tl[T_LOG_DLO]; out_lo = 0.0f; }
+    if (v >= sc.hi) { out = fmaf(v - sc.hi, tl[T_DHI], sc.hi); ld = tl[T_LOG_DHI]; out_lo = 0.0f; }
+  }
+}
+template <int K, bool FAST>
+__device__ __forceinline__ void table_spline_precise(const float* tab, const double* tabd, v2f v, v2f v_lo,
+                                                     const SplineConsts& sc, v2f& out, v2f& ld, v2f& out_lo) {
+  float ox, lx, rx, oy, ly, ry;
+  table_spline_precise<K, FAST>(tab, tabd, v.x, v_lo.x, sc, ox, lx, rx);
+  table_spline_precise<K, FAST>(tab, tabd, v.y, v_lo.y, sc, oy, ly, ry);
   out = v2f{ox, oy}; ld = v2f{lx, ly}; out_lo = v2f{rx, ry};
 }
 

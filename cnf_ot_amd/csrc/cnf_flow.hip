@@ -48,6 +48,10 @@ template <class R> struct FlowArgsT {
 typedef FlowArgsT<float> FlowArgs;
 typedef FlowArgsT<double> FlowArgsD;
 
+template <class A> __device__ __forceinline__ bool gate_closed(const A& a) {
+  return a.gate && ((*a.gate == a.gate_epoch) ? 1 : 0) != a.gate_want;
+}
+
 // ---------------------------------------------------------------------------
 // prepare_kernel: params (flat, caller-owned) -> prepared model buffer.
 // Thread 0 normalises the `first` spline in float64; all threads snapshot the
@@ -135,8 +139,6 @@ __global__ void prepare_kernel(const float* __restrict__ params, float* __restri
     prep[tab_off(F_D0, K) + k] = (float)dl[k];
     prep[tab_off(F_D1, K) + k] = (float)dl[k + 1];
     prep[tab_off(F_L2S, K) + k] = (float)(2.0 * log(s));
-    prep[tab_off(F_X0L, K) + k] = (float)(xk[k] - (double)(float)xk[k]);
-    prep[tab_off(F_Y0L, K) + k] = (float)(yk[k] - (double)(float)yk[k]);
   }
   for (int k = 0; k <= K; ++k) {
     prep[tab_off(F_XK, K) + k] = (float)xk[k];
@@ -219,7 +221,8 @@ __device__ __forceinline__ v2f hsum(v2f v) { return v; }
 template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false, bool PRECISE = false>
 __device__ __forceinline__ T flow_pass(const ModelArgs& a, const typename Lanes<T>::real* tab,
                                        typename Lanes<T>::real*& U, typename Lanes<T>::real*& O, T c,
-                                       const double* e2tab = nullptr, BaseAcc<T>* bacc = nullptr) {
+                                       const double* e2tab = nullptr, const double* tabd = nullptr,
+                                       typename Lanes<T>::real* LO = nullptr, BaseAcc<T>* bacc = nullptr) {
   typedef typename Lanes<T>::real R;
   static_assert(!PRECISE || (TO_BASE && !std::is_same<T, double>::value), "precise path: data -> base, fp32 kernels");
   const SplineConstsT<R>& sc = sc_of<R>(a);
@@ -238,11 +241,21 @@ __device__ __forceinline__ T flow_pass(const ModelArgs& a, const typename Lanes<
     R* cu = U + SPL * threadIdx.x;
     R* co = O + SPL * threadIdx.x;
     T o, ld, olo;
-    table_spline<K, INV, FAST, T, PRECISE>(tab, lds_get<T>(cu, first_idx, TS), sc, o, ld, olo);
+    const bool last = step == a.L - 1;
+    [[maybe_unused]] R* clo = nullptr;
+    if constexpr (PRECISE) {
+      // LO[d]: what rounding dimension d's value to fp32 dropped (this thread's column; in place: read as the
+      // layer's input, overwritten with its output).  The data themselves are exact fp32: zero before layer 1.
+      clo = LO + SPL * threadIdx.x;
+      const T vlo = step == 0 ? splat<T>(0.0f) : lds_get<T>(clo, first_idx, TS);
+      table_spline_precise<K, FAST>(tab, tabd, lds_get<T>(cu, first_idx, TS), vlo, sc, o, ld, olo);
+      lds_put(clo, first_idx, TS, olo);
+      if (last) bacc->add(o, olo);
+    } else {
+      table_spline<K, INV, FAST, T>(tab, lds_get<T>(cu, first_idx, TS), sc, o, ld);
+    }
     lds_put(co, first_idx, TS, o);
     acc += ld;
-    const bool last = step == a.L - 1;
-    if constexpr (PRECISE) { if (last) bacc->add(o, olo); }
     uniform_ptr w = weights + l * a.per_layer;
     const float* wq = a.wq + l * a.per_layer_q;
     for (int d = 1; d < D; ++d) {
@@ -256,7 +269,9 @@ __device__ __forceinline__ T flow_pass(const ModelArgs& a, const typename Lanes<
         w += cond_floats(d, H, a.M, P);
       }
       if constexpr (PRECISE) {
-        cond_spline_precise<K, FAST, false>(th, lds_get<T>(cu, i, TS), sc, a.scd, e2tab, o, ld, olo);
+        const T vlo = step == 0 ? splat<T>(0.0f) : lds_get<T>(clo, i, TS);
+        cond_spline_precise<K, FAST, false>(th, lds_get<T>(cu, i, TS), vlo, sc, a.scd, e2tab, o, ld, olo);
+        lds_put(clo, i, TS, olo);
         if (last) bacc->add(o, olo);
       } else {
         cond_spline<K, INV, FAST, T>(th, lds_get<T>(cu, i, TS), sc, o, ld);
@@ -301,10 +316,15 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
   R* O = U + a.m.D * TS;
   if (gate_closed(a)) return;
   for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = table_of<R>(a.m)[i];
-  double* e2tab = nullptr;
-  if constexpr (PRECISE) {                 // [.. U O][2^(-i/32) table]; HDR and D * TS are even: 8-byte aligned
-    e2tab = reinterpret_cast<double*>(O + a.m.D * TS);
+  [[maybe_unused]] double* e2tab = nullptr;
+  [[maybe_unused]] double* tabd = nullptr;
+  [[maybe_unused]] R* LO = nullptr;
+  if constexpr (PRECISE) {      // [.. U O][LO][2^(-i/32) table][float64 `first` table]; HDR, D * TS even: 8-byte aligned
+    LO = O + a.m.D * TS;
+    e2tab = reinterpret_cast<double*>(LO + a.m.D * TS);
+    tabd = e2tab + EXP2_N;
     for (int i = threadIdx.x; i < EXP2_N; i += TILE) e2tab[i] = a.m.e2tab[i];
+    for (int i = threadIdx.x; i < HDR; i += TILE) tabd[i] = a.m.tabd[i];
   }
 
   const int64_t n_tiles = (a.B + TS - 1) / TS;
@@ -319,7 +339,7 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
     T base = splat<T>(0.0f);
     if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = base_logprob<T>(U + SPL * threadIdx.x, a.m.D, TS);
     BaseAcc<T> bacc;
-    const T acc = flow_pass<H, K, TO_BASE, FAST, T, MFMA, PRECISE>(a.m, tab, U, O, c, e2tab, &bacc);
+    const T acc = flow_pass<H, K, TO_BASE, FAST, T, MFMA, PRECISE>(a.m, tab, U, O, c, e2tab, tabd, LO, &bacc);
     if (a.aux) {
       T r = acc;
       if (a.aux_mode == AUX_LOGPROB) {
@@ -336,6 +356,100 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// flow_dpar_kernel: base -> data (sample / sample_and_log_prob / forward) for D >= 3 with the D - 1 conditioners
+// of a layer on different WAVES.  In this direction every conditioner of a layer sees the layer's INPUTS
+// (autoregressive.py:109-136: `y[perm[:d]]` of the incoming event), so they are independent of each other; the
+// one-sample-per-lane kernel above runs them back to back on one lane and needs ~2 M samples to fill the chip
+// (config 4's per-GPU shard is 32 768: 512 waves on 1 024 SIMDs, each with a chain of 2 x 9 conditioners).
+// Here a workgroup owns a tile of 64 * SPL samples and has one wave per conditioned dimension (d = 1 + wave,
+// strided if D - 1 exceeds the wave count): the weights stay wave-uniform (scalar operands), a layer costs one
+// conditioner + one spline per wave and a barrier, and the shard becomes 256-512 workgroups of D - 1 waves.  The
+// waves' log-det shares are summed in a fixed order (deterministic).
+// ---------------------------------------------------------------------------
+template <class R>
+__device__ __forceinline__ void tile_load_n(const R* __restrict__ g, R* U, int D, uint32_t magic, int TS,
+                                            int64_t tile_start, int64_t B, int nthreads) {
+  const int64_t base = tile_start * D;
+  const int n_el = (int)(B - tile_start < TS ? B - tile_start : TS) * D;
+  for (int e = threadIdx.x; e < TS * D; e += nthreads) {
+    const int s = magic ? (int)__umulhi((uint32_t)e, magic) : e, d = e - s * D;
+    U[d * TS + s] = e < n_el ? g[base + e] : (R)0;
+  }
+}
+template <class R>
+__device__ __forceinline__ void tile_store_n(R* __restrict__ g, const R* U, int D, uint32_t magic, int TS,
+                                             int64_t tile_start, int64_t B, int nthreads) {
+  const int64_t base = tile_start * D;
+  const int n_el = (int)(B - tile_start < TS ? B - tile_start : TS) * D;
+  for (int e = threadIdx.x; e < n_el; e += nthreads) {
+    const int s = magic ? (int)__umulhi((uint32_t)e, magic) : e, d = e - s * D;
+    g[base + e] = U[d * TS + s];
+  }
+}
+
+template <int H, int K, bool FAST, class T>
+__global__ __launch_bounds__(1024) void flow_dpar_kernel(const FlowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int HDR = hdr_floats(K), P = 3 * K + 1, SPL = Lanes<T>::N, TS = 64 * SPL;
+  const int D = a.m.D, L = a.m.L, NT = blockDim.x, NW = NT >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float* tab = lds;
+  float* U = lds + HDR;
+  float* O = U + D * TS;
+  float* LD = O + D * TS;                                  // [NW][TS] log-det shares
+  if (gate_closed(a)) return;
+  for (int i = threadIdx.x; i < HDR; i += NT) tab[i] = a.m.prep[i];
+  const SplineConsts& sc = a.m.sc;
+  uniform_ptr weights = as_uniform(a.m.prep + HDR);
+  // floats of the conditioners 1 .. d-1 of a layer: sum_{q<d} ((1 + q) H + C), C = the d-independent part
+  const int64_t cpart = cond_floats(0, H, a.m.M, P) - H;
+
+  const int64_t n_tiles = (a.B + TS - 1) / TS;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t tile_start = tile * TS;
+    const int64_t i = tile_start + SPL * lane;
+    __syncthreads();
+    tile_load_n<float>(a.in, U, D, a.div_magic, TS, tile_start, a.B, NT);
+    const T c = load_cond<T>(a, tile_start, i);
+    __syncthreads();
+    T base = splat<T>(0.0f);
+    if (wave == 0 && a.aux_mode == AUX_LOGPROB && a.aux) base = base_logprob<T>(U + SPL * lane, D, TS);
+    T acc = splat<T>(0.0f);
+    for (int l = 0; l < L; ++l) {
+      const bool odd = l & 1;                              // flows.py:141-143 perms
+      const int first_idx = odd ? D - 1 : 0, idx_step = odd ? -1 : 1;
+      const float* cu = U + SPL * lane;
+      float* co = O + SPL * lane;
+      T o, ld;
+      if (wave == 0) {
+        table_spline<K, true, FAST, T>(tab, lds_get<T>(cu, first_idx, TS), sc, o, ld);
+        lds_put(co, first_idx, TS, o);
+        acc += ld;
+      }
+      for (int d = 1 + wave; d < D; d += NW) {
+        const int64_t off = l * a.m.per_layer + (int64_t)H * ((d - 1) + (int64_t)d * (d - 1) / 2) + (d - 1) * cpart;
+        T th[P];
+        conditioner<H, P, T>(weights + off, d, a.m.M, c, cu, first_idx, idx_step, TS, th);
+        const int idx = first_idx + d * idx_step;
+        cond_spline<K, true, FAST, T>(th, lds_get<T>(cu, idx, TS), sc, o, ld);
+        lds_put(co, idx, TS, o);
+        acc += ld;
+      }
+      __syncthreads();
+      float* t = U; U = O; O = t;
+    }
+    if (a.aux) lds_put(LD + wave * TS + SPL * lane, 0, TS, acc);
+    __syncthreads();
+    if (a.aux && wave == 0) {
+      T tot = splat<T>(0.0f);
+      for (int w = 0; w < NW; ++w) tot += lds_get<T>(LD + w * TS + SPL * lane, 0, TS);
+      store_aux(a.aux, i, a.B, a.aux_mode == AUX_LOGPROB ? base - tot : tot);
+    }
+    if (a.out) tile_store_n<float>(a.out, U, D, a.div_magic, TS, tile_start, a.B, NT);
+  }
+}
 
 // ---------------------------------------------------------------------------
 // flow_pwl_kernel: the dim-2 flow with the conditioner read from the exact
@@ -372,10 +486,6 @@ __global__ void cond_uniform_kernel(const float* __restrict__ c, int64_t B, uint
   if (__syncthreads_or(diff) && threadIdx.x == 0) *flag = epoch;
 }
 
-template <class A> __device__ __forceinline__ bool gate_closed(const A& a) {
-  return a.gate && ((*a.gate == a.gate_epoch) ? 1 : 0) != a.gate_want;
-}
-
 // Stage the L tables of (set, slice) into LDS: header arrays + the rows in use, at most PWL_LROWS.
 __device__ __forceinline__ void pwl_stage(float* tbl, const float* __restrict__ g0, int L, int tid, int nthreads) {
   for (int l = 0; l < L; ++l) {
@@ -395,23 +505,30 @@ template <int K, bool TO_BASE, bool FAST, bool PRECISE = false>
 __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, const float* __restrict__ gtbl,
                                             int L, const SplineConsts& sc, v2f& u0, v2f& u1,
                                             const PreciseConsts* pc = nullptr, const double* e2tab = nullptr,
-                                            BaseAcc<v2f>* bacc = nullptr) {
+                                            const double* tabd = nullptr, BaseAcc<v2f>* bacc = nullptr) {
   constexpr bool INV = !TO_BASE;
   static_assert(!PRECISE || TO_BASE, "precise path: data -> base");
   v2f acc = splat<v2f>(0.0f);
+  [[maybe_unused]] v2f lo0 = splat<v2f>(0.0f), lo1 = lo0;      // precise path: what rounding u0 / u1 to fp32 dropped
   for (int step = 0; step < L; ++step) {
     const int l = TO_BASE ? L - 1 - step : step;
     const bool odd = l & 1;                     // flows.py:141-143 perms
     const v2f uf = odd ? u1 : u0, uo = odd ? u0 : u1;
-    v2f of, oo, ld, olo;
-    table_spline<K, INV, FAST, v2f, PRECISE>(tab, uf, sc, of, ld, olo);
+    v2f of, oo, ld, olo_f, olo_o;
+    if constexpr (PRECISE) {
+      table_spline_precise<K, FAST>(tab, tabd, uf, odd ? lo1 : lo0, sc, of, ld, olo_f);
+      if (step == L - 1) bacc->add(of, olo_f);
+    } else {
+      table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld);
+    }
     acc += ld;
-    if constexpr (PRECISE) { if (step == L - 1) bacc->add(of, olo); }
     v2f th[PWL_P];
     pwl_eval(tbl + l * PWL_LTBL, gtbl + (int64_t)l * PWL_TBL, TO_BASE ? of : uf, th);
     if constexpr (PRECISE) {
-      cond_spline_precise<K, FAST, true>(th, uo, sc, *pc, e2tab, oo, ld, olo);
-      if (step == L - 1) bacc->add(oo, olo);
+      cond_spline_precise<K, FAST, true>(th, uo, odd ? lo0 : lo1, sc, *pc, e2tab, oo, ld, olo_o);
+      if (step == L - 1) bacc->add(oo, olo_o);
+      lo0 = odd ? olo_o : olo_f;
+      lo1 = odd ? olo_f : olo_o;
     } else {
       cond_spline_masked<K, INV, FAST>(th, uo, sc, oo, ld);
     }
@@ -434,10 +551,13 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
   if (gate_closed(a)) return;
   for (int i = tid; i < hdr_floats(K); i += PWL_THREADS) tab[i] = table_of<float>(a.m)[i];
   const SplineConsts& sc = sc_of<float>(a.m);
-  double* e2tab = nullptr;
+  [[maybe_unused]] double* e2tab = nullptr;
+  [[maybe_unused]] double* tabd = nullptr;
   if constexpr (PRECISE) {                 // after the L tables (HDR and PWL_LTBL are even: 8-byte aligned)
     e2tab = reinterpret_cast<double*>(tbl + L * PWL_LTBL);
+    tabd = e2tab + EXP2_N;
     for (int i = tid; i < EXP2_N; i += PWL_THREADS) e2tab[i] = a.m.e2tab[i];
+    for (int i = tid; i < hdr_floats(K); i += PWL_THREADS) tabd[i] = a.m.tabd[i];
   }
 
   const int total = a.n_slices * a.tiles_per_slice;
@@ -467,7 +587,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
     if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = (u0 * u0 + u1 * u1) * -0.5f - (float)(2 * HALF_LOG_2PI);
     BaseAcc<v2f> bacc;
     const v2f acc = flow2_tables<K, TO_BASE, FAST, PRECISE>(tab, tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, sc,
-                                                            u0, u1, &a.m.scd, e2tab, &bacc);
+                                                            u0, u1, &a.m.scd, e2tab, tabd, &bacc);
     if (a.aux) {
       v2f r = acc;
       if constexpr (PRECISE) { if (a.aux_mode == AUX_LOGPROB) r = bacc.log_prob(acc, 2); }
@@ -917,6 +1037,7 @@ extern "C" int cnf_model_create(const CnfConfig* cfg, CnfModel** out) {
   // and at equal peak rate the packed-VALU conditioner is 4-5 % faster.
   m->use_mfma = 0;
   m->use_pwl = 1;
+  m->use_dpar = 1;
   // (D = 1 would need 2^32: encoded as 0, tile_load/tile_store take s = e)
   m->div_magic = cfg->dim == 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + (uint64_t)cfg->dim - 1) / (uint64_t)cfg->dim);
   m->per_layer_q = 0; m->mfma_off = 0;
@@ -1052,6 +1173,14 @@ extern "C" int cnf_model_set_precise(CnfModel* m, int on) {
   return CNF_OK;
 }
 
+/* Internal knob: wave-per-dimension kernel for base -> data at dim >= 3: 1 = by batch size (default),
+ * 2 = always, 0 = never. */
+extern "C" int cnf_model_set_dpar(CnfModel* m, int mode) {
+  if (!m || mode < 0 || mode > 2) return CNF_ERR_INVALID;
+  m->use_dpar = mode;
+  return CNF_OK;
+}
+
 /* Internal knob: 0 = choose by batch size, 1 / 2 = force samples per lane. */
 extern "C" int cnf_model_set_samples_per_lane(CnfModel* m, int spl) {
   if (!m || spl < 0 || spl > 2) return CNF_ERR_INVALID;
@@ -1092,6 +1221,39 @@ static int samples_per_lane(const CnfModel* m, int64_t B) {
     hipLaunchKernelGGL(KERNEL, dim3((unsigned)(GRID)), dim3(TILE), LDS, STREAM, ARGS); \
   } while (0)
 
+// flow_dpar_kernel: D >= 3, base -> data, packed-VALU conditioner, hardware transcendentals.  Chosen (use_dpar
+// = 1) while the one-sample-per-lane kernel would leave the chip under-filled.
+static int launch_flow_dpar(CnfModel* m, const FlowArgs& a, hipStream_t stream) {
+  const int D = m->cfg.dim;
+  if (D < 3 || !m->fast_math || m->use_mfma || !m->use_dpar) return CNF_ERR_UNSUPPORTED;
+  // below ~8 waves per SIMD of single-lane work the wave-per-dimension form wins (measured crossover: DESIGN.md)
+  if (m->use_dpar == 1 && a.B > (int64_t)m->num_cus * 4 * 64 * 8) return CNF_ERR_UNSUPPORTED;
+  int nw = D - 1;
+  if (nw > 16) nw = 16;
+  const int spl = (m->force_spl == 1 || m->force_spl == 2) ? m->force_spl : (a.B >= (int64_t)m->num_cus * 128 ? 2 : 1);
+  const int64_t ts = 64 * spl;
+  const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + (2 * D + nw) * ts) * sizeof(float);
+  if (lds > 64 * 1024) return CNF_ERR_UNSUPPORTED;
+  int64_t grid = (a.B + ts - 1) / ts;
+  const int64_t cap = (int64_t)m->num_cus * 8;
+  if (grid > cap) grid = cap;
+#define X(HH, KK)                                                                             \
+  if (m->cfg.hidden_size == HH && m->cfg.num_bins == KK) {                                    \
+    if (!a.gate) m->last_path = CNF_PATH_DPAR;                                                \
+    ProfScope ps(m, stream, false, a.B, CNF_PATH_DPAR);                                       \
+    if (spl == 2) hipLaunchKernelGGL((flow_dpar_kernel<HH, KK, true, v2f>), dim3((unsigned)grid), dim3(64 * nw), lds, stream, a);   \
+    else hipLaunchKernelGGL((flow_dpar_kernel<HH, KK, true, float>), dim3((unsigned)grid), dim3(64 * nw), lds, stream, a);          \
+    ps.done();                                                                                \
+    return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;                            \
+  }
+  CNF_KERNEL_CONFIGS(X)
+#undef X
+  return CNF_ERR_UNSUPPORTED;
+}
+
+// LDS of the precise position path beyond the tile: the 2^(-i/32) table and the float64 `first` table
+static size_t precise_lds_bytes(int K) { return sizeof(double) * (size_t)(cnf::EXP2_N + hdr_floats(K)); }
+
 template <bool TO_BASE>
 static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stream) {
   const int64_t ts = (int64_t)TILE * spl;
@@ -1102,7 +1264,7 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
   constexpr bool PR = TO_BASE;                 // the precise position path exists for the data -> base direction
   const bool precise = PR && m->precise;
   const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * ts) * sizeof(float) +
-                     (precise ? sizeof(double) * cnf::EXP2_N : 0);
+                     (precise ? precise_lds_bytes(m->cfg.num_bins) + sizeof(float) * a.m.D * ts : 0);
   if (m->fast_math && m->use_mfma && m->mfma_off > 0 && m->cfg.hidden_size == 16 && m->cfg.num_bins == 5) {
     if (!a.gate) m->last_path = CNF_PATH_MFMA;
     ProfScope ps(m, stream, false, a.B, CNF_PATH_MFMA);
@@ -1206,7 +1368,7 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
   const int L = m->cfg.num_layers;
   const bool precise = to_base && m->precise;
   size_t lds = (size_t)(((cnf::hdr_floats(5) + 3) & ~3) + L * cnf::PWL_LTBL) * sizeof(float) +
-               (precise ? sizeof(double) * cnf::EXP2_N : 0);
+               (precise ? precise_lds_bytes(5) : 0);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
   const int64_t slice_len = c_block < B ? c_block : B;
   const int64_t n_slices = (B + slice_len - 1) / slice_len;
@@ -1312,12 +1474,16 @@ static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, 
   a.div_magic = m->div_magic;
   int spl = m->fast_math ? samples_per_lane(m, B) : 1;
   // two samples per lane double the LDS tile: fall back when it would not fit
-  if (spl == 2 && (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * TILE * 2) * sizeof(float) +
-                      sizeof(double) * cnf::EXP2_N > 160 * 1024) spl = 1;
+  if (spl == 2 && (size_t)(hdr_floats(m->cfg.num_bins) + 3 * a.m.D * TILE * 2) * sizeof(float) +
+                      precise_lds_bytes(m->cfg.num_bins) > 160 * 1024) spl = 1;
   if (c_block >= B) a.c_mode = C_SINGLE;
   else if (c_block == 1) a.c_mode = C_PER_SAMPLE;
   else if (c_block % (TILE * spl) == 0) a.c_mode = C_TILE_UNIFORM;
   else a.c_mode = C_GENERIC;
+  if (!to_base) {
+    const int r = launch_flow_dpar(m, a, (hipStream_t)stream);
+    if (r != CNF_ERR_UNSUPPORTED) return r;
+  }
   return to_base ? launch_flow<true>(m, a, spl, (hipStream_t)stream)
                  : launch_flow<false>(m, a, spl, (hipStream_t)stream);
 }

@@ -152,6 +152,11 @@ class FlowEngine:
     _capi.check(self.lib.cnf_model_set_pwl(self._h, int(mode)), "cnf_model_set_pwl")
     self._pwl_mode = int(mode)
 
+  def set_dpar(self, mode: int) -> None:
+    """Wave-per-dimension kernel for base -> data at dim >= 3: 1 = chosen by
+    batch size (default), 2 = always, 0 = never."""
+    _capi.check(self.lib.cnf_model_set_dpar(self._h, int(mode)), "cnf_model_set_dpar")
+
   def set_precise(self, on: bool) -> None:
     """cnf_model_set_precise: float64 position path of log_prob / inverse
     (default on), or plain fp32."""

@@ -179,3 +179,86 @@ def main2():
 if __name__ == "__main__":
   print("---- data = the flow's own samples (the GPU test's distribution) ----")
   main2()
+
+
+def main3():
+  """does rounding the intermediate layer outputs to fp32 matter? (positions in f64 otherwise)"""
+  import types
+  f32, f64 = np.float32, np.float64
+  g = globals()
+  orig = g["rqs_fwd"]
+  for seed in (0, 1, 2, 3, 4):
+    rng = np.random.default_rng(seed)
+    params = rng.normal(0, 0.2, 1200).astype(f32).astype(f64)
+    noise = rng.normal(size=(65536, 2)).astype(f32).astype(f64)
+    y = sample_f64(params, noise, 0.5).astype(f32).astype(f64)
+    ref, xr = log_prob(params, y, 0.5, f64, f64, f64, f64)
+    res = {}
+    for tag, rnd in (("carry f64", False), ("round layer outputs to f32", True)):
+      def wrapped(x, xk, yk, dl, dp, dl_t, _o=orig, _r=rnd):
+        yy, ld = _o(x, xk, yk, dl, dp, dl_t)
+        return (yy.astype(f32).astype(f64) if _r else yy), ld
+      g["rqs_fwd"] = wrapped
+      lp, x = log_prob(params, y, 0.5, f32, f64, f64, f32)
+      e = np.abs(lp - ref)
+      res[tag] = (e.max(), np.quantile(e, .999))
+    g["rqs_fwd"] = orig
+    print(f"seed {seed}: " + "; ".join(f"{k}: max {a:.2e} p99.9 {b:.2e}" for k, (a, b) in res.items()))
+
+
+if __name__ == "__main__":
+  print("---- intermediate rounding ----")
+  main3()
+
+
+def rqs_fwd_mixed(x, xk, yk, dl, dp, dl_t, refine=True):
+  """the GPU's precise path: corner and offset in float64, the in-bin rational in fp32"""
+  f32, f64 = np.float32, np.float64
+  x = x.astype(f64)
+  k = np.clip((x[:, None] >= xk[:, 1:-1]).sum(1), 0, K - 1)
+  r = np.arange(len(x))
+  x0, x1, y0, y1 = xk[r, k], xk[r, k + 1], yk[r, k], yk[r, k + 1]
+  d0, d1 = dl[r, k].astype(f32), dl[r, k + 1].astype(f32)
+  bw, bh = (x1 - x0).astype(f32), (y1 - y0).astype(f32)
+  dxf = (x - x0).astype(f32)
+  if refine:
+    s = (bh.astype(f64) / bw.astype(f64)).astype(f32)
+    z = np.clip((dxf.astype(f64) / bw.astype(f64)).astype(f32), 0, 1)
+  else:
+    ibw = (f32(1) / bw)
+    s = bh * ibw
+    z = np.clip(dxf * ibw, f32(0), f32(1))
+  z1mz = z - z * z
+  st = d1 + d0 - f32(2) * s
+  den = s + st * z1mz
+  num = bh * (s * z * z + d0 * z1mz)
+  inc = (num.astype(f64) / den.astype(f64)).astype(f32) if refine else num * (f32(1) / den)
+  y = y0 + inc.astype(f64)
+  ld = f32(2) * np.log(s) + np.log(d1 * z * z + f32(2) * s * z1mz + d0 * (f32(1) - z) ** 2) - f32(2) * np.log(den)
+  return y, ld.astype(f64)
+
+
+def main4():
+  f32, f64 = np.float32, np.float64
+  g = globals()
+  orig = g["rqs_fwd"]
+  for seed in (0, 1, 2, 3, 4):
+    rng = np.random.default_rng(seed)
+    params = rng.normal(0, 0.2, 1200).astype(f32).astype(f64)
+    noise = rng.normal(size=(65536, 2)).astype(f32).astype(f64)
+    y = sample_f64(params, noise, 0.5).astype(f32).astype(f64)
+    ref, xr = log_prob(params, y, 0.5, f64, f64, f64, f64)
+    out = []
+    for tag, fn in (("in-bin f64", orig), ("in-bin fp32, exact quotients", lambda *a: rqs_fwd_mixed(*a, refine=True)),
+                    ("in-bin fp32, rcp", lambda *a: rqs_fwd_mixed(*a, refine=False))):
+      g["rqs_fwd"] = fn
+      lp, x = log_prob(params, y, 0.5, f32, f64, f64, f32)
+      e = np.abs(lp - ref)
+      out.append(f"{tag}: max {e.max():.2e} p99.9 {np.quantile(e, .999):.2e}")
+    g["rqs_fwd"] = orig
+    print(f"seed {seed}: " + "; ".join(out))
+
+
+if __name__ == "__main__":
+  print("---- in-bin evaluation precision ----")
+  main4()

@@ -506,6 +506,41 @@ def test_dim10_batch_vs_oracle(dev):
   assert _err(lp, lp_ref).max() <= 2e-5      # 20 splines summed instead of 4
 
 
+@pytest.mark.parametrize("D,B", [(3, 5000), (10, 32768 + 77), (24, 700)])
+def test_wave_per_dimension_kernel(dev, D, B):
+  """flow_dpar_kernel (base -> data at dim >= 3, one wave per conditioned
+  dimension; D = 24 strides 23 conditioners over 16 waves): both lane widths,
+  uniform and per-sample conditions, ragged batch, vs the oracle and vs the
+  one-sample-per-lane kernel; forward / sample_and_log_prob / sample."""
+  import oracle
+  fcfg, ocfg = _cfg_pair(D=D)
+  rng = np.random.default_rng(100 + D)
+  params = rng.normal(0, 0.12 if D <= 10 else 0.05, oracle.param_count(ocfg)).astype(np.float32).astype(np.float64)
+  noise = rng.normal(size=(B, D)).astype(np.float32)
+  c_per = rng.uniform(0, 1, B).astype(np.float32)
+  eng = _engine(fcfg, params, dev)
+  for cond, c_host, c_block in ((torch.tensor([0.3], device=dev), [0.3], B), (_t(c_per, dev), c_per.astype(np.float64), 1)):
+    y_ref, lp_ref = oracle.sample_logprob(ocfg, params, noise.astype(np.float64), c_host)     # c of length B: per sample
+    eng.set_dpar(0)
+    y0, lp0 = eng.sample_logprob(_t(noise, dev), cond)
+    assert eng.last_path() in ("mlp1", "mlp2")
+    eng.set_dpar(2)
+    for spl in (1, 2):
+      eng.set_samples_per_lane(spl)
+      y, lp = eng.sample_logprob(_t(noise, dev), cond)
+      assert eng.last_path() == "dpar"
+      assert _err(y, y_ref).max() <= TOL_Y and _err(lp, lp_ref).max() <= (2e-5 if D <= 10 else 5e-5)
+      assert (y - y0).abs().max().item() <= 2e-5 and (lp - lp0).abs().max().item() <= 2e-5
+      yf, fldj = eng.forward_logdet(_t(noise, dev), cond)
+      assert torch.equal(yf, y)
+      ys, _ = eng.sample_logprob(_t(noise, dev), cond, want_logp=False)
+      assert torch.equal(ys, y)
+    eng.set_samples_per_lane(0)
+  eng.set_dpar(1)                       # default: by batch size -- these batches are small
+  eng.sample_logprob(_t(noise, dev), torch.tensor([0.3], device=dev))
+  assert eng.last_path() == "dpar"
+
+
 @pytest.mark.parametrize("pwl", [0, 2], ids=["mlp", "pwl"])
 def test_wild_params_no_worse_than_fp32_port(dev, golden_dir, pwl):
   """SURVEY.md 8(d) cfg 2 (ii) literal: N(0, 0.5^2) on every tensor, seed 42
