@@ -1226,8 +1226,9 @@ static int samples_per_lane(const CnfModel* m, int64_t B) {
 static int launch_flow_dpar(CnfModel* m, const FlowArgs& a, hipStream_t stream) {
   const int D = m->cfg.dim;
   if (D < 3 || !m->fast_math || m->use_mfma || !m->use_dpar) return CNF_ERR_UNSUPPORTED;
-  // below ~8 waves per SIMD of single-lane work the wave-per-dimension form wins (measured crossover: DESIGN.md)
-  if (m->use_dpar == 1 && a.B > (int64_t)m->num_cus * 4 * 64 * 8) return CNF_ERR_UNSUPPORTED;
+  // measured crossover with the one-sample-per-lane kernel (MI355X, D = 3 and D = 10, scripts/exp_dim10.py):
+  // between 131 072 and 524 288 samples; 512 samples per CU
+  if (m->use_dpar == 1 && a.B > (int64_t)m->num_cus * 512) return CNF_ERR_UNSUPPORTED;
   int nw = D - 1;
   if (nw > 16) nw = 16;
   const int spl = (m->force_spl == 1 || m->force_spl == 2) ? m->force_spl : (a.B >= (int64_t)m->num_cus * 128 ? 2 : 1);
