@@ -143,25 +143,25 @@ UNFUSED_SCORE_MIN_DIM = 6
 
 
 def _score_terms_unfused(ctx, conds, batch_size, dt, dx, coef_score, loss_coef, drift=None):
-  """per-slice sums of  sum_d ((r2-r1)/dt + coef_score * score_d(r3) - drift_d(r3))^2  as torch ops
-  over flow passes; with ctx.grad, back-propagated through cnf_pass_vjp."""
+  """per-slice sums of  sum_d ((r2-r1)/dt + coef_score * score_d(r3) - drift_d(r3))^2  from three kinds of
+  launches: ONE base -> data pass over the 3 x S x count points (conditions t -+ dt/2 and t; at this size the
+  wave-per-dimension kernel), ONE central-difference score launch over the S x count points r3 (its 2 D
+  evaluation points per sample are generated inside the kernel), and a handful of elementwise torch ops; with
+  ctx.grad, back-propagated through cnf_pass_vjp / cnf_logprob_fd_vjp."""
   from . import autograd as ag
   be = ctx.be
   z, _, count = ctx.noise(batch_size)
   S, D = len(conds), z.shape[1]
+  n = S * count
   t = torch.as_tensor(np.asarray(conds, dtype=np.float32), device=z.device)
   flat = be._flat.detach().requires_grad_(ctx.grad is not None)
-  zs = z.repeat(S, 1)                                         # the same draw for every slice
   tt = t.repeat_interleave(count)                             # per-sample condition
+  z3 = z.repeat(3 * S, 1)                                     # the same draw for every slice and condition
+  c3 = torch.cat([tt - 0.5 * dt, tt + 0.5 * dt, tt])
   with torch.set_grad_enabled(ctx.grad is not None):
-    r1, _ = ag.flow_forward(be, flat, zs, tt - 0.5 * dt)
-    r2, _ = ag.flow_forward(be, flat, zs, tt + 0.5 * dt)
-    r3, _ = ag.flow_forward(be, flat, zs, tt)
-    eye = torch.eye(D, device=z.device) * (0.5 * dx)
-    pts = torch.cat([(r3[:, None, :] + eye[None]).reshape(-1, D), (r3[:, None, :] - eye[None]).reshape(-1, D)])
-    lp = ag.log_prob(be, flat, pts, tt.repeat_interleave(D).repeat(2))
-    n = S * count * D
-    score = ((lp[:n] - lp[n:]) / dx).reshape(S * count, D)
+    r, _ = ag.flow_forward(be, flat, z3, c3)
+    r1, r2, r3 = r[:n], r[n:2 * n], r[2 * n:]
+    score = ag.logprob_fd(be, flat, r3, tt, dx)
     u = (r2 - r1) / dt + coef_score * score
     if drift is not None:
       u = u - drift(r3)

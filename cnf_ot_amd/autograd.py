@@ -57,6 +57,35 @@ def log_prob(engine: FlowEngine, flat_params: torch.Tensor, value: torch.Tensor,
   return (-0.5 * x * x).sum(1) - 0.5 * x.shape[1] * 1.8378770664093453 + ildj
 
 
+class _LogProbFD(torch.autograd.Function):
+  """score[i, d] = (log_prob(r_i + dx/2 e_d) - log_prob(r_i - dx/2 e_d)) / dx (applications.py:264-273):
+  forward cnf_logprob_fd, backward cnf_logprob_fd_vjp -- the 2 D evaluation points per sample exist only inside
+  the kernels."""
+
+  @staticmethod
+  def forward(ctx, flat, pts, c, engine: FlowEngine, dx: float):
+    engine.load(flat)
+    pts = pts.contiguous()
+    score = engine.logprob_fd(pts, c, dx)
+    ctx.save_for_backward(flat, pts, c)
+    ctx.engine, ctx.dx = engine, dx
+    return score
+
+  @staticmethod
+  def backward(ctx, gbar):
+    flat, pts, c = ctx.saved_tensors
+    eng = ctx.engine
+    eng.load(flat)
+    grad = torch.zeros_like(flat)
+    pts_bar = eng.logprob_fd_vjp(pts, c, ctx.dx, gbar.contiguous(), grad, want_pts_bar=ctx.needs_input_grad[1])
+    return (grad if ctx.needs_input_grad[0] else None), pts_bar, None, None, None
+
+
+def logprob_fd(engine: FlowEngine, flat_params: torch.Tensor, pts: torch.Tensor, c, dx: float):
+  """Central-difference score of log_prob, differentiable in flat_params and pts."""
+  return _LogProbFD.apply(flat_params, pts, _cond_tensor(engine, c), engine, float(dx))
+
+
 def _cond_tensor(engine, c):
   if not torch.is_tensor(c):
     c = torch.as_tensor(c, dtype=torch.float32)

@@ -254,8 +254,22 @@ __device__ __forceinline__ void dense_T(uniform_ptr W, const float (&in)[16], fl
 // ---------------------------------------------------------------------------
 constexpr int STG = 68;   // row stride of the staging tiles: conflict-free ds_read_b128
 
+// The accumulator tile lives in the wave's gradient slab in global memory (L2): its read is a dependent ~1-2 us
+// round trip if issued where it is needed, so conditioner_bwd issues the reads of all three tiles (and bias rows)
+// up front (wgrad_fetch) and they arrive while the wave recomputes and back-propagates.
+struct WgradAcc { f4 acc; float bias; };
+
+__device__ __forceinline__ WgradAcc wgrad_fetch(const float* __restrict__ dW, int n_rows, const float* __restrict__ db) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+  WgradAcc r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) r.acc[q] = (4 * g + q < n_rows) ? dW[(4 * g + q) * 16 + i] : 0.0f;
+  r.bias = (db && g == 0) ? db[i] : 0.0f;
+  return r;
+}
+
 __device__ __forceinline__ void wgrad_mfma(float* stage, const float (&a)[16], const float (&b)[16],
-                                           float* __restrict__ dW, int n_rows, float* __restrict__ db) {
+                                           float* __restrict__ dW, int n_rows, float* __restrict__ db, WgradAcc pre) {
   const int lane = threadIdx.x & 63;
   float* sa = stage;
   float* sb = stage + 16 * STG;
@@ -271,9 +285,7 @@ __device__ __forceinline__ void wgrad_mfma(float* stage, const float (&a)[16], c
     bv[n] = *reinterpret_cast<const f4*>(sb + i * STG + 16 * g + 4 * n);
   }
   __builtin_amdgcn_wave_barrier();
-  f4 acc;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = (4 * g + r < n_rows) ? dW[(4 * g + r) * 16 + i] : 0.0f;
+  f4 acc = pre.acc;
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
 #pragma unroll
@@ -287,8 +299,22 @@ __device__ __forceinline__ void wgrad_mfma(float* stage, const float (&a)[16], c
     for (int n = 0; n < 4; ++n) sum += (bv[n][0] + bv[n][1]) + (bv[n][2] + bv[n][3]);
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-    if (g == 0) db[i] += sum;
+    if (g == 0) db[i] = pre.bias + sum;
   }
+}
+
+// the three accumulator tiles of one conditioner (output, hidden, first layer), fetched before the wave starts
+// recomputing the conditioner: ~1 500 instructions of cover for the L2 round trip
+struct WgradPre { WgradAcc o, h, f; };
+__device__ __forceinline__ WgradPre wgrad_prefetch(const float* __restrict__ gw, int d) {
+  const int o_b0 = (1 + d) * 16, o_w1 = o_b0 + 16, o_b1 = o_w1 + 256, o_wo = o_b1 + 16, o_bo = o_wo + 256;
+  WgradPre p;
+  p.o = wgrad_fetch(gw + o_wo, 16, gw + o_bo);
+  p.h = wgrad_fetch(gw + o_w1, 16, gw + o_b1);
+  p.f = wgrad_fetch(gw, d + 2, nullptr);
+  // pin the loads here: the compiler would sink them to their first use
+  asm volatile("" : "+v"(p.o.acc), "+v"(p.h.acc), "+v"(p.f.acc));
+  return p;
 }
 
 // ---------------------------------------------------------------------------
@@ -303,18 +329,19 @@ template <bool WGRAD = true>
 __device__ __forceinline__ void conditioner_bwd(uniform_ptr w, int d, float c, const float* col, int first_idx,
                                                 int idx_step, int stride, const float (&h1)[16],
                                                 const float (&h2)[16], const float (&tb)[16], float* adj_col,
-                                                float* __restrict__ gw, float* stage) {
+                                                float* __restrict__ gw, float* stage, const WgradPre& pre) {
   w = launder(w);
   const int o_b0 = (1 + d) * 16, o_w1 = o_b0 + 16, o_b1 = o_w1 + 256, o_wo = o_b1 + 16, o_bo = o_wo + 256;
+  [[maybe_unused]] const WgradAcc pre_o = pre.o, pre_1 = pre.h, pre_0 = pre.f;
   // output layer
-  if constexpr (WGRAD) wgrad_mfma(stage, h2, tb, gw + o_wo, 16, gw + o_bo);
+  if constexpr (WGRAD) wgrad_mfma(stage, h2, tb, gw + o_wo, 16, gw + o_bo, pre_o);
   float g2[16];
   dense_T(w + o_wo, tb, g2);
 #pragma unroll
   for (int i = 0; i < 16; ++i) g2[i] = h2[i] > 0.0f ? g2[i] : 0.0f;
   materialize<16>(g2);
   // hidden layer
-  if constexpr (WGRAD) wgrad_mfma(stage, h1, g2, gw + o_w1, 16, gw + o_b1);
+  if constexpr (WGRAD) wgrad_mfma(stage, h1, g2, gw + o_w1, 16, gw + o_b1, pre_1);
   float g1[16];
   dense_T(w + o_w1, g2, g1);
 #pragma unroll
@@ -333,7 +360,7 @@ __device__ __forceinline__ void conditioner_bwd(uniform_ptr w, int d, float c, c
     }
 #pragma unroll
     for (int r = 1; r < 16; ++r) in[r] = (r == d + 1) ? 1.0f : in[r];
-    wgrad_mfma(stage, in, g1, gw, d + 2, nullptr);
+    wgrad_mfma(stage, in, g1, gw, d + 2, nullptr, pre_0);
   }
   for (int q = 0; q < d; ++q) {          // adjoints of the conditioning inputs
     float wr[16];

@@ -44,6 +44,11 @@ template <class R> struct FlowArgsT {
   const uint32_t* gate;
   uint32_t gate_epoch;
   int32_t gate_want;
+  // finite-difference mode (cnf_logprob_fd; data -> base only): `in` holds B / fd2 points r_i and evaluation
+  // point j = i * fd2 + 2 d + s is r_i + (s ? -fd_h : +fd_h) e_d (fd2 = 2 D); aux[i * D + d] receives
+  // (log_prob(j) - log_prob(j + 1)) * fd_inv_dx.  fd2 = 0: off.
+  int32_t fd2;
+  R fd_h, fd_inv_dx;
 };
 typedef FlowArgsT<float> FlowArgs;
 typedef FlowArgsT<double> FlowArgsD;
@@ -188,6 +193,10 @@ __device__ __forceinline__ void tile_store(R* __restrict__ g, const R* U, int D,
 
 template <class R>
 __device__ __forceinline__ R load_cond1(const FlowArgsT<R>& a, int64_t tile_start, int64_t i) {
+  if (a.fd2) {                                   // evaluation point -> its base point's condition
+    if (a.c_mode == C_SINGLE) return a.c[0];
+    return i < a.B ? a.c[(i / a.fd2) / a.c_block] : (R)0;
+  }
   switch (a.c_mode) {
     case C_SINGLE: return a.c[0];
     case C_PER_SAMPLE: return i < a.B ? a.c[i] : (R)0;
@@ -206,6 +215,32 @@ template <> __device__ __forceinline__ v2f load_cond<v2f>(const FlowArgs& a, int
   if (a.c_mode == C_SINGLE || a.c_mode == C_TILE_UNIFORM) return splat<v2f>(load_cond1(a, ts, i));
   return v2f{load_cond1(a, ts, i), load_cond1(a, ts, i + 1)};
 }
+
+// finite-difference mode: the tile's evaluation points are built from the base points on the fly
+template <class R>
+__device__ __forceinline__ void tile_load_fd(const FlowArgsT<R>& a, R* U, int D, uint32_t magic, int TS, int64_t tile_start) {
+  const int n_el = (int)(a.B - tile_start < TS ? a.B - tile_start : TS) * D;
+  for (int e = threadIdx.x; e < TS * D; e += TILE) {
+    const int s = magic ? (int)__umulhi((uint32_t)e, magic) : e, d = e - s * D;
+    R v = (R)0;
+    if (e < n_el) {
+      const int64_t j = tile_start + s, i = j / a.fd2;
+      const int k = (int)(j - i * a.fd2);
+      v = a.in[i * D + d];
+      if ((k >> 1) == d) v += (k & 1) ? -a.fd_h : a.fd_h;
+    }
+    U[d * TS + s] = v;
+  }
+}
+// (log_prob(+) - log_prob(-)) / dx of the pair (j, j + 1), j even
+__device__ __forceinline__ void store_fd(const FlowArgs& a, int64_t j, v2f lp) {
+  if (j + 1 < a.B) a.aux[j >> 1] = (lp.x - lp.y) * a.fd_inv_dx;
+}
+__device__ __forceinline__ void store_fd(const FlowArgs& a, int64_t j, float lp) {
+  const float other = __shfl_xor(lp, 1, 64);
+  if (!(j & 1) && j + 1 < a.B) a.aux[j >> 1] = (lp - other) * a.fd_inv_dx;
+}
+__device__ __forceinline__ void store_fd(const FlowArgsD&, int64_t, double) {}
 
 __device__ __forceinline__ float hsum(float v) { return v; }
 __device__ __forceinline__ v2f hsum(v2f v) { return v; }
@@ -332,7 +367,8 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
     const int64_t tile_start = tile * TS;
     const int64_t i = tile_start + SPL * threadIdx.x;
     __syncthreads();                       // previous tile's stores are done with U/O
-    tile_load<R>(a.in, U, a.m.D, a.div_magic, TS, tile_start, a.B);
+    if (TO_BASE && !PRECISE && a.fd2) tile_load_fd<R>(a, U, a.m.D, a.div_magic, TS, tile_start);
+    else tile_load<R>(a.in, U, a.m.D, a.div_magic, TS, tile_start, a.B);
     const T c = load_cond<T>(a, tile_start, i);
     __syncthreads();
 
@@ -347,7 +383,8 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
         if constexpr (PRECISE) r = bacc.log_prob(acc, a.m.D);
         else r = TO_BASE ? base_logprob<T>(U + SPL * threadIdx.x, a.m.D, TS) + acc : base - acc;
       }
-      store_aux(a.aux, i, a.B, r);
+      if (TO_BASE && !PRECISE && a.fd2) store_fd(a, i, r);
+      else store_aux(a.aux, i, a.B, r);
     }
     if (a.out) {
       __syncthreads();
@@ -1471,6 +1508,7 @@ static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, 
   a.in = in; a.c = c; a.out = out; a.aux = aux;
   a.B = B; a.c_block = c_block;
   a.gate = gate; a.gate_epoch = gate_epoch; a.gate_want = 1;     // MLP kernel: only if a difference was stamped
+  a.fd2 = 0; a.fd_h = 0.f; a.fd_inv_dx = 0.f;
   a.aux_mode = aux_mode;
   a.div_magic = m->div_magic;
   int spl = m->fast_math ? samples_per_lane(m, B) : 1;
@@ -1509,6 +1547,34 @@ extern "C" int cnf_sample_logprob(CnfModel* m, const float* noise, const float* 
                                   float* y, float* logp, int64_t B, void* stream) {
   if (!y) return CNF_ERR_INVALID;
   return run_flow(m, false, noise, c, c_block, y, logp, AUX_LOGPROB, B, stream);
+}
+
+extern "C" int cnf_logprob_fd(CnfModel* m, const float* pts, const float* c, int64_t c_block, float dx,
+                              float* score, int64_t B, void* stream) {
+  if (!m || !pts || !c || !score || B < 0 || c_block < 1 || !(dx > 0.f)) return CNF_ERR_INVALID;
+  if (!m->params_set) return CNF_ERR_INVALID;
+  if (B == 0) return CNF_OK;
+  const int D = m->cfg.dim;
+  if (B * 2 * D >= ((int64_t)1 << 40)) return CNF_ERR_INVALID;
+  if (wait_for_params(m, (hipStream_t)stream) != CNF_OK) return CNF_ERR_HIP;
+  FlowArgs a;
+  a.m = model_args(m);
+  a.in = pts; a.c = c; a.out = nullptr; a.aux = score;
+  a.B = B * 2 * D;                              // evaluation points
+  a.c_block = c_block;
+  a.aux_mode = AUX_LOGPROB;
+  a.div_magic = m->div_magic;
+  a.gate = nullptr; a.gate_epoch = 0; a.gate_want = 0;
+  a.fd2 = 2 * D; a.fd_h = 0.5f * dx; a.fd_inv_dx = 1.0f / dx;
+  a.c_mode = c_block >= B ? C_SINGLE : C_GENERIC;
+  int spl = m->fast_math ? samples_per_lane(m, a.B) : 1;
+  if (spl == 2 && (size_t)(hdr_floats(m->cfg.num_bins) + 2 * D * TILE * 2) * sizeof(float) > 160 * 1024) spl = 1;
+  // plain fp32: the difference of two nearby log_prob values cancels what the precise position path would fix
+  const int precise = m->precise;
+  m->precise = 0;
+  const int r = launch_flow<true>(m, a, spl, (hipStream_t)stream);
+  m->precise = precise;
+  return r;
 }
 
 extern "C" int cnf_fill_normal(uint64_t seed, uint64_t first_element, int64_t n, float* out,
@@ -1679,6 +1745,7 @@ static int run_flow_f64(CnfModel* m, bool to_base, const double* in, const doubl
   a.in = in; a.c = c; a.out = out; a.aux = aux;
   a.B = B; a.c_block = c_block; a.aux_mode = aux_mode; a.div_magic = m->div_magic;
   a.gate = nullptr; a.gate_epoch = 0; a.gate_want = 0;
+  a.fd2 = 0; a.fd_h = 0.0; a.fd_inv_dx = 0.0;
   if (c_block >= B) a.c_mode = C_SINGLE;
   else if (c_block == 1) a.c_mode = C_PER_SAMPLE;
   else if (c_block % TILE == 0) a.c_mode = C_TILE_UNIFORM;

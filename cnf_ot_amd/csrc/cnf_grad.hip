@@ -21,7 +21,11 @@ namespace cnf {
 
 constexpr int GK = 5;              // bins
 constexpr int GP = 3 * GK + 1;     // 16 spline parameters
-constexpr int GTS = TILE;          // one sample per lane
+// One sample per lane; a tile = one workgroup's samples = blockDim.x (64, 128 or 256: the host picks the size that
+// puts the most waves on a CU -- a tile's LDS working set is (L + 3 .. L + 9) x D floats per sample plus 8.7 KB of
+// MFMA staging per wave, and at 1 wave per SIMD a wave issues at half rate with every latency exposed).
+#define GTS ((int)blockDim.x)
+constexpr int GTS_MAX = TILE;
 
 struct GradArgs {
   ModelArgs m;
@@ -42,7 +46,7 @@ __device__ __forceinline__ void tile_load1(const float* __restrict__ g, float* U
                                            int64_t tile_start, int64_t B) {
   const int64_t base = tile_start * D;
   const int n_el = (int)(B - tile_start < GTS ? B - tile_start : GTS) * D;
-  for (int e = threadIdx.x; e < GTS * D; e += TILE) {
+  for (int e = threadIdx.x; e < GTS * D; e += GTS) {
     const int s = magic ? (int)__umulhi((uint32_t)e, magic) : e, d = e - s * D;
     U[d * GTS + s] = e < n_el ? g[base + e] : 0.0f;
   }
@@ -118,6 +122,9 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab,
       off -= cond_floats(d, 16, 2, GP);
       const int i = first_idx + d * idx_step;
       uniform_ptr w = weights + l * a.per_layer + off;
+      float* gw = WGRAD ? gslab + GP + l * a.per_layer + off : nullptr;
+      WgradPre pre;
+      if constexpr (WGRAD) pre = wgrad_prefetch(gw, d);
       float h1[16], h2[16], th[GP], tb[GP];
       conditioner_keep(w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, h1, h2, th);
       float vb;
@@ -125,7 +132,7 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab,
       else vb = cond_spline_bwd<GK, true, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
       au[i * GTS] += vb;
       conditioner_bwd<WGRAD>(w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, h1, h2, tb, to_base ? ao : au,
-                             gslab + GP + l * a.per_layer + off, stage);
+                             gw, stage, pre);
     }
     float vb0;
     if (to_base) vb0 = table_spline_bwd<GK, false>(tab, cu[first_idx * GTS], co[first_idx * GTS], ao[first_idx * GTS],
@@ -185,7 +192,7 @@ enum Role {
 };
 
 template <bool FAST>
-__global__ __launch_bounds__(TILE, 1) void grad_kernel(const GradArgs a) {
+__global__ __launch_bounds__(GTS_MAX, 1) void grad_kernel(const GradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HDR = hdr_floats(GK);
   const int D = a.m.D, L = a.m.L;
@@ -200,10 +207,10 @@ __global__ __launch_bounds__(TILE, 1) void grad_kernel(const GradArgs a) {
   float* R3b = R3 + DT;
   float* Ub = R3b + DT;
   float* stage = Ub + DT + (threadIdx.x >> 6) * (2 * 16 * STG);
-  for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = a.m.prep[i];
+  for (int i = threadIdx.x; i < HDR; i += GTS) tab[i] = a.m.prep[i];
   const int tid = threadIdx.x;
   const int kind = a.spec.kind;
-  float* gslab = a.slabs + ((int64_t)blockIdx.x * 4 + (tid >> 6)) * a.n_params;
+  float* gslab = a.slabs + ((int64_t)blockIdx.x * (GTS >> 6) + (tid >> 6)) * a.n_params;
   FirstAcc fa;
 #pragma unroll
   for (int j = 0; j < GK; ++j) { fa.Wb[j] = 0.0f; fa.Hb[j] = 0.0f; }
@@ -407,12 +414,18 @@ struct VjpArgs {
   int64_t B, c_block;
   int32_t to_base;
   uint32_t div_magic;
+  // finite-difference mode (cnf_logprob_fd_vjp): pts holds B / fd2 base points r_i; the pass differentiated is
+  // log_prob at the evaluation point j = i * fd2 + 2 d + s (r_i -+ fd_h e_d) with seed +-gbar[i, d] * fd_inv_dx;
+  // xbar[i, :] receives the SUM of the adjoints of r_i's fd2 evaluation points.  fd2 = 0: off.
+  int32_t fd2;
+  float fd_h, fd_inv_dx;
+  const float* gbar;     // [B / fd2, D]
 };
 
 // WGRAD=true additionally accumulates the parameter gradient of the pass (the
 // backward of a differentiable flow op: cnf_pass_vjp).
 template <bool FAST, bool WGRAD>
-__global__ __launch_bounds__(TILE, WGRAD ? 1 : 2) void vjp_kernel(const VjpArgs a) {
+__global__ __launch_bounds__(GTS_MAX, WGRAD ? 1 : 2) void vjp_kernel(const VjpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HDR = hdr_floats(GK);
   const int D = a.m.D, L = a.m.L, DT = D * GTS;
@@ -421,32 +434,67 @@ __global__ __launch_bounds__(TILE, WGRAD ? 1 : 2) void vjp_kernel(const VjpArgs 
   float* Aa = St + (L + 1) * DT;
   float* Ab = Aa + DT;
   float* stage = WGRAD ? Ab + DT + (threadIdx.x >> 6) * (2 * 16 * STG) : nullptr;
-  float* gslab = WGRAD ? a.slabs + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * a.n_params : nullptr;
-  for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = a.m.prep[i];
+  float* gslab = WGRAD ? a.slabs + ((int64_t)blockIdx.x * (GTS >> 6) + (threadIdx.x >> 6)) * a.n_params : nullptr;
+  for (int i = threadIdx.x; i < HDR; i += GTS) tab[i] = a.m.prep[i];
   const int tid = threadIdx.x;
   FirstAcc fa;      // WGRAD=false: written, never read: removed by the compiler
 #pragma unroll
   for (int j = 0; j < GK; ++j) { fa.Wb[j] = 0.0f; fa.Hb[j] = 0.0f; }
 #pragma unroll
   for (int j = 0; j <= GK; ++j) fa.Db[j] = 0.0f;
-  const int64_t n_tiles = (a.B + GTS - 1) / GTS;
+  // finite-difference mode: a tile holds whole groups of fd2 evaluation points (tp <= GTS of them)
+  const int tp = a.fd2 ? (GTS / a.fd2) * a.fd2 : GTS;
+  const int64_t n_tiles = (a.B + tp - 1) / tp;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t tile_start = tile * GTS;
+    const int64_t tile_start = tile * tp;
     const int64_t i = tile_start + tid;
     __syncthreads();
-    tile_load1(a.pts, St, D, a.div_magic, tile_start, a.B);
-    if (a.ybar) tile_load1(a.ybar, Aa, D, a.div_magic, tile_start, a.B);
-    else for (int e = tid; e < DT; e += TILE) Aa[e] = 0.0f;
-    const float c = i < a.B ? a.c[a.c_block >= a.B ? 0 : i / a.c_block] : 0.0f;
-    const float ld_bar = (a.ldbar && i < a.B) ? a.ldbar[i] : 0.0f;
+    float c, ld_bar;
+    if (a.fd2) {
+      const bool valid = tid < tp && i < a.B;
+      const int64_t ib = valid ? i / a.fd2 : 0;
+      const int k = (int)(i - ib * a.fd2), dd = k >> 1;
+      for (int e = 0; e < D; ++e) {
+        float v = valid ? a.pts[ib * D + e] : 0.0f;
+        if (e == dd) v += (k & 1) ? -a.fd_h : a.fd_h;
+        St[e * GTS + tid] = v;
+        Aa[e * GTS + tid] = 0.0f;
+      }
+      const int64_t n_base = a.B / a.fd2;
+      c = valid ? a.c[a.c_block >= n_base ? 0 : ib / a.c_block] : 0.0f;
+      ld_bar = valid ? ((k & 1) ? -a.gbar[ib * D + dd] : a.gbar[ib * D + dd]) * a.fd_inv_dx : 0.0f;
+    } else {
+      tile_load1(a.pts, St, D, a.div_magic, tile_start, a.B);
+      if (a.ybar) tile_load1(a.ybar, Aa, D, a.div_magic, tile_start, a.B);
+      else for (int e = tid; e < DT; e += GTS) Aa[e] = 0.0f;
+      c = i < a.B ? a.c[a.c_block >= a.B ? 0 : i / a.c_block] : 0.0f;
+      ld_bar = (a.ldbar && i < a.B) ? a.ldbar[i] : 0.0f;
+    }
     __syncthreads();
     pass_fwd_stash<FAST>(a.m, tab, St, c, a.to_base != 0);
+    if (a.fd2) {       // log_prob = sum -x^2/2 + ildj: the adjoint of the recovered base point is -ld_bar x
+      const float* sL = St + L * DT + tid;
+      for (int e = 0; e < D; ++e) Aa[e * GTS + tid] = -ld_bar * sL[e * GTS];
+    }
     float* ain = pass_bwd<FAST, WGRAD>(a.m, tab, St, Aa, Ab, ld_bar, c, a.to_base != 0, gslab, stage, fa);
     __syncthreads();
-    if (a.xbar) {      // coalesced store of the input adjoints
+    if (a.fd2) {       // xbar[i, e] = sum over the fd2 evaluation points of base point i (fixed order: deterministic)
+      if (a.xbar) {
+        const int groups = tp / a.fd2;
+        const int64_t first_base = tile_start / a.fd2, n_base = a.B / a.fd2;
+        for (int idx = tid; idx < groups * D; idx += GTS) {
+          const int il = idx / D, e = idx - il * D;
+          if (first_base + il < n_base) {
+            float sum = 0.0f;
+            for (int k = 0; k < a.fd2; ++k) sum += ain[e * GTS + il * a.fd2 + k];
+            a.xbar[(first_base + il) * D + e] = sum;
+          }
+        }
+      }
+    } else if (a.xbar) {      // coalesced store of the input adjoints
       const int64_t base = tile_start * D;
       const int n_el = (int)(a.B - tile_start < GTS ? a.B - tile_start : GTS) * D;
-      for (int e = tid; e < GTS * D; e += TILE) {
+      for (int e = tid; e < GTS * D; e += GTS) {
         const int s = a.div_magic ? (int)__umulhi((uint32_t)e, a.div_magic) : e, d = e - s * D;
         if (e < n_el) a.xbar[base + e] = ain[d * GTS + s];
       }
@@ -538,16 +586,33 @@ __global__ void adam_kernel(float* __restrict__ params, const float* __restrict_
 
 using namespace cnf;
 
-static size_t grad_lds_bytes(int D, int L) {
-  // tab + noise + (L+1) stashes + 2 adjoint buffers + velocity, r3, r3_bar, u_bar + 4 MFMA staging areas
-  return (size_t)(hdr_floats(GK) + D * GTS * (1 + (L + 1) + 6) + 4 * 2 * 16 * STG) * sizeof(float);
+#undef GTS
+static size_t grad_lds_bytes(int D, int L, int ts = GTS_MAX) {
+  // tab + noise + (L+1) stashes + 2 adjoint buffers + velocity, r3, r3_bar, u_bar + one MFMA staging area per wave
+  return (size_t)(hdr_floats(GK) + D * ts * (1 + (L + 1) + 6) + (ts / 64) * 2 * 16 * STG) * sizeof(float);
+}
+static size_t vjp_lds_bytes(int D, int L, int ts, bool wgrad) {
+  return (size_t)(hdr_floats(GK) + D * ts * ((L + 1) + 2) + (wgrad ? (ts / 64) * 2 * 16 * STG : 0)) * sizeof(float);
+}
+// The tile size (threads per workgroup) that puts the most waves on a CU: LDS allows 160 KB / lds(ts) workgroups
+// of ts / 64 waves; the backward kernels' ~230 VGPRs allow 8 waves (2 per SIMD).  Ties go to the larger tile.
+template <class F> static int pick_tile(F lds_of) {
+  int best = 64, best_waves = 0;
+  for (int ts = GTS_MAX; ts >= 64; ts >>= 1) {
+    const size_t b = lds_of(ts);
+    if (b > 160 * 1024) continue;
+    int waves = (int)((160 * 1024) / b) * (ts / 64);
+    if (waves > 8) waves = 8;
+    if (waves > best_waves) { best_waves = waves; best = ts; }
+  }
+  return best;
 }
 
 extern "C" int cnf_grad_supported(const CnfConfig* c) {
   // hidden 16 / 2 hidden layers / 5 bins (the MFMA weight-gradient tiles are 16x16), dim <= 14 (the
   // first layer's inputs + bias row fit 16 MFMA rows), and the tile's LDS working set within one CU
   return c && c->hidden_size == 16 && c->mlp_num_layers == 2 && c->num_bins == 5 && c->dim >= 1 && c->dim <= 14 &&
-         c->num_layers >= 1 && grad_lds_bytes(c->dim, c->num_layers) <= 160 * 1024;
+         c->num_layers >= 1 && grad_lds_bytes(c->dim, c->num_layers, 64) <= 160 * 1024;
 }
 
 extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const float* pts, int pts_shared,
@@ -576,18 +641,19 @@ extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const f
   a.slabs = m->grad_slabs; a.n_params = m->n_params;
   a.B = B; a.n_slices = n_slices; a.pts_slice_stride = pts_shared ? 0 : B;
   a.scale = scale; a.div_magic = m->div_magic;
-  int64_t grid = ((B + GTS - 1) / GTS) * n_slices;
-  if (grid > m->grad_max_blocks) grid = m->grad_max_blocks;
-  const size_t lds = grad_lds_bytes(D, L);
+  const int ts = pick_tile([&](int t) { return grad_lds_bytes(D, L, t); });
+  int64_t grid = ((B + ts - 1) / ts) * n_slices;
+  if (grid > m->grad_max_blocks * 4 / (ts / 64)) grid = m->grad_max_blocks * 4 / (ts / 64);
+  const size_t lds = grad_lds_bytes(D, L, ts);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
-  const int64_t n_slabs = grid * 4;
+  const int64_t n_slabs = grid * (ts / 64);
   if (hipMemsetAsync(m->grad_slabs, 0, sizeof(float) * (size_t)(n_slabs * m->n_params), stream) != hipSuccess) return CNF_ERR_HIP;
   if (m->fast_math) {
     if (!ensure_lds(grad_kernel<true>, lds)) return CNF_ERR_HIP;
-    hipLaunchKernelGGL(grad_kernel<true>, dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+    hipLaunchKernelGGL(grad_kernel<true>, dim3((unsigned)grid), dim3(ts), lds, stream, a);
   } else {
     if (!ensure_lds(grad_kernel<false>, lds)) return CNF_ERR_HIP;
-    hipLaunchKernelGGL(grad_kernel<false>, dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+    hipLaunchKernelGGL(grad_kernel<false>, dim3((unsigned)grid), dim3(ts), lds, stream, a);
   }
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
   const int fb = (int)((m->n_params + 31) / 32);
@@ -632,30 +698,31 @@ static int pass_vjp_impl(CnfModel* m, int to_base, const float* pts, const float
   a.m = model_args(m); a.pts = pts; a.c = c; a.ybar = ybar; a.ldbar = ldbar; a.xbar = xbar;
   a.slabs = m->grad_slabs; a.n_params = m->n_params;
   a.B = B; a.c_block = c_block; a.to_base = to_base ? 1 : 0; a.div_magic = m->div_magic;
+  a.fd2 = 0; a.fd_h = 0.f; a.fd_inv_dx = 0.f; a.gbar = nullptr;
   const int D = m->cfg.dim, L = m->cfg.num_layers;
-  size_t lds = (size_t)(hdr_floats(GK) + D * GTS * ((L + 1) + 2)) * sizeof(float);
-  int64_t grid = (B + GTS - 1) / GTS;
+  const int ts = pick_tile([&](int t) { return vjp_lds_bytes(D, L, t, grad != nullptr); });
+  size_t lds = vjp_lds_bytes(D, L, ts, grad != nullptr);
+  int64_t grid = (B + ts - 1) / ts;
   if (!grad) {
-    if (grid > (int64_t)m->num_cus * 4) grid = (int64_t)m->num_cus * 4;
+    if (grid > (int64_t)m->num_cus * 4 * (GTS_MAX / ts)) grid = (int64_t)m->num_cus * 4 * (GTS_MAX / ts);
     if (m->fast_math) {
       if (!ensure_lds(vjp_kernel<true, false>, lds)) return CNF_ERR_UNSUPPORTED;
-      hipLaunchKernelGGL((vjp_kernel<true, false>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+      hipLaunchKernelGGL((vjp_kernel<true, false>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
     } else {
       if (!ensure_lds(vjp_kernel<false, false>, lds)) return CNF_ERR_UNSUPPORTED;
-      hipLaunchKernelGGL((vjp_kernel<false, false>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+      hipLaunchKernelGGL((vjp_kernel<false, false>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
     }
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
   }
-  lds += (size_t)(4 * 2 * 16 * STG) * sizeof(float);
-  if (grid > m->grad_max_blocks) grid = m->grad_max_blocks;
-  const int64_t n_slabs = grid * 4;
+  if (grid > m->grad_max_blocks * 4 / (ts / 64)) grid = m->grad_max_blocks * 4 / (ts / 64);
+  const int64_t n_slabs = grid * (ts / 64);
   if (hipMemsetAsync(m->grad_slabs, 0, sizeof(float) * (size_t)(n_slabs * m->n_params), stream) != hipSuccess) return CNF_ERR_HIP;
   if (m->fast_math) {
     if (!ensure_lds(vjp_kernel<true, true>, lds)) return CNF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((vjp_kernel<true, true>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+    hipLaunchKernelGGL((vjp_kernel<true, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
   } else {
     if (!ensure_lds(vjp_kernel<false, true>, lds)) return CNF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((vjp_kernel<false, true>), dim3((unsigned)grid), dim3(TILE), lds, stream, a);
+    hipLaunchKernelGGL((vjp_kernel<false, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
   }
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
   const int fb = (int)((m->n_params + 31) / 32);
@@ -674,4 +741,45 @@ extern "C" int cnf_pass_vjp(CnfModel* m, int to_base, const float* pts, const fl
                             const float* ybar, const float* ldbar, float* xbar, float* grad, const float* params,
                             int64_t B, void* stream) {
   return pass_vjp_impl(m, to_base, pts, c, c_block, ybar, ldbar, xbar, grad, params, B, stream);
+}
+
+extern "C" int cnf_logprob_fd_vjp(CnfModel* m, const float* pts, const float* c, int64_t c_block, float dx,
+                                  const float* gbar, float* pts_bar, float* grad, const float* params, int64_t B,
+                                  void* stream_) {
+  if (!m || !pts || !c || !gbar || B < 0 || c_block < 1 || !(dx > 0.f) || (!pts_bar && !grad)) return CNF_ERR_INVALID;
+  if (!grad || !params) return CNF_ERR_INVALID;       // the parameter gradient is what this entry point is for
+  if (!m->params_set) return CNF_ERR_INVALID;
+  if (!cnf_grad_supported(&m->cfg)) return CNF_ERR_UNSUPPORTED;
+  if (B == 0) return CNF_OK;
+  if (!m->grad_slabs) return CNF_ERR_INVALID;          // cnf_grad_enable first
+  hipStream_t stream = (hipStream_t)stream_;
+  if (wait_for_params(m, stream) != CNF_OK) return CNF_ERR_HIP;
+  const int D = m->cfg.dim, L = m->cfg.num_layers;
+  VjpArgs a;
+  a.m = model_args(m); a.pts = pts; a.c = c; a.ybar = nullptr; a.ldbar = nullptr; a.xbar = pts_bar;
+  a.slabs = m->grad_slabs; a.n_params = m->n_params;
+  a.B = B * 2 * D; a.c_block = c_block; a.to_base = 1; a.div_magic = m->div_magic;
+  a.fd2 = 2 * D; a.fd_h = 0.5f * dx; a.fd_inv_dx = 1.0f / dx; a.gbar = gbar;
+  int ts = pick_tile([&](int t) { return vjp_lds_bytes(D, L, t, true); });
+  while (ts < 2 * D && ts < GTS_MAX) ts <<= 1;          // a tile holds at least one group of 2 D evaluation points
+  if (ts < 2 * D) return CNF_ERR_UNSUPPORTED;
+  const size_t lds = vjp_lds_bytes(D, L, ts, true);
+  if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
+  const int64_t tp = (ts / (2 * D)) * (2 * D);
+  int64_t grid = (a.B + tp - 1) / tp;
+  if (grid > m->grad_max_blocks * 4 / (ts / 64)) grid = m->grad_max_blocks * 4 / (ts / 64);
+  const int64_t n_slabs = grid * (ts / 64);
+  if (hipMemsetAsync(m->grad_slabs, 0, sizeof(float) * (size_t)(n_slabs * m->n_params), stream) != hipSuccess) return CNF_ERR_HIP;
+  if (m->fast_math) {
+    if (!ensure_lds(vjp_kernel<true, true>, lds)) return CNF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((vjp_kernel<true, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
+  } else {
+    if (!ensure_lds(vjp_kernel<false, true>, lds)) return CNF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((vjp_kernel<false, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
+  }
+  if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
+  const int fb = (int)((m->n_params + 31) / 32);
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, n_slabs, m->n_params, params,
+                     grad, (double)m->sc.span_eff, (double)m->sc.sp_offset);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }

@@ -25,6 +25,15 @@ Flow = namedtuple("Flow", [
 
 _MASK64 = (1 << 64) - 1
 
+# In-place writers that bypass torch's version counter (Adam.apply through the C ABI) bump the epoch of the
+# memory they wrote; FlowEngine.load compares it.  Keyed by data_ptr: an entry can only go stale when the memory
+# is recycled, which costs a spurious re-preparation, never a missed one (the engine keeps its tensor alive).
+_WRITE_EPOCH = {}
+
+
+def mark_updated(flat: torch.Tensor) -> None:
+  _WRITE_EPOCH[flat.data_ptr()] = _WRITE_EPOCH.get(flat.data_ptr(), 0) + 1
+
 
 def _c_config(cfg: FlowConfig) -> _capi.CnfConfig:
   return _capi.CnfConfig(cfg.dim, cfg.num_layers, cfg.hidden_size, cfg.mlp_num_layers,
@@ -92,8 +101,10 @@ class FlowEngine:
     has written to it since (torch's version counter; in-place writers that
     bypass torch -- Adam.apply through the C ABI -- call `mark_updated`)."""
     flat = flatten(self.cfg, params, self.device)
-    key = (flat._version, getattr(flat, "_cnf_epoch", 0))
-    if flat is self._flat and key == self._flat_key:
+    # the same memory (this engine keeps `_flat` alive, so its address cannot have been recycled), same torch
+    # version (aliases made by detach() share the counter), no C-side write since
+    key = (flat.data_ptr(), flat._version, _WRITE_EPOCH.get(flat.data_ptr(), 0))
+    if self._flat is not None and key == self._flat_key:
       return self
     with torch.cuda.device(self.device):
       _capi.check(self.lib.cnf_model_set_params(self._h, flat.data_ptr(), _stream_ptr(self.device)),
@@ -371,6 +382,42 @@ class FlowEngine:
                                           self._flat.data_ptr() if grad is not None else None, B,
                                           _stream_ptr(self.device)), "cnf_pass_vjp")
     return xbar
+
+  def logprob_fd(self, pts, cond, dx: float) -> torch.Tensor:
+    """cnf_logprob_fd: the central-difference score [B, D] of log_prob at pts."""
+    pts = self._points(pts, "logprob_fd")
+    B = pts.shape[0]
+    c, c_block = self.cond(cond, B)
+    score = torch.empty_like(pts)
+    if B > 0:
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_logprob_fd(self._h, pts.data_ptr(), c.data_ptr(), c_block, float(dx),
+                                            score.data_ptr(), B, _stream_ptr(self.device)), "cnf_logprob_fd")
+    return score
+
+  def logprob_fd_vjp(self, pts, cond, dx: float, gbar, grad, want_pts_bar=True):
+    """cnf_logprob_fd_vjp: backward of `logprob_fd` for the output adjoint gbar
+    [B, D]: returns pts_bar (or None) and accumulates the parameter gradient
+    into `grad`."""
+    if self._flat is None:
+      raise RuntimeError("load(params) before asking for gradients")
+    if not getattr(self, "_grad_enabled", False):
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
+      self._grad_enabled = True
+    pts = self._points(pts, "logprob_fd_vjp")
+    B = pts.shape[0]
+    c, c_block = self.cond(cond, B)
+    gbar = self._check_out(self._points(gbar, "gbar"), pts.shape, "gbar")
+    self._check_out(grad, (self.cfg.param_count(),), "grad")
+    pts_bar = torch.empty_like(pts) if want_pts_bar else None
+    if B > 0:
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_logprob_fd_vjp(self._h, pts.data_ptr(), c.data_ptr(), c_block, float(dx),
+                                                gbar.data_ptr(), pts_bar.data_ptr() if want_pts_bar else None,
+                                                grad.data_ptr(), self._flat.data_ptr(), B,
+                                                _stream_ptr(self.device)), "cnf_logprob_fd_vjp")
+    return pts_bar
 
   def jacobian(self, pts, cond, to_base=False) -> torch.Tensor:
     """[B, D, D] Jacobian d out_i / d in_j of a flow pass: D vector-Jacobian products."""

@@ -12,7 +12,7 @@ from typing import Any, Callable, Dict, Tuple
 import torch
 
 from . import _capi, applications
-from .flows import RQSFlow, FlowModel, _stream_ptr
+from .flows import RQSFlow, FlowModel, _stream_ptr, mark_updated
 from .params import Params
 
 # config/mfc.yaml:6-40 (the checked-in defaults)
@@ -95,7 +95,7 @@ class Adam:
                                     state.nu.data_ptr(), params.flat.numel(), self.lr, self.b1, self.b2, self.eps,
                                     state.step, _stream_ptr(dev)), "cnf_adam_step")
     # the kernel wrote params.flat behind torch's back: engines must re-prepare (FlowEngine.load)
-    params.flat._cnf_epoch = getattr(params.flat, "_cnf_epoch", 0) + 1
+    mark_updated(params.flat)
     return state
 
 

@@ -292,6 +292,24 @@ int cnf_pass_vjp(CnfModel *m, int to_base, const float *pts, const float *c,
                  float *xbar, float *grad, const float *params, int64_t B,
                  void *stream);
 
+/* The score of the flow's density by central differences, the way the reference
+ * forms it (kinetic_with_score_loss_fn / flow_matching_loss_fn,
+ * applications.py:264-273; utils.py:366-381):
+ *   score[i, d] = (log_prob(r_i + dx/2 e_d) - log_prob(r_i - dx/2 e_d)) / dx
+ * for B points r_i [B, D] (the 2 D evaluation points of a point are generated in
+ * the kernel: 2 D B flow passes spread over the whole GPU, nothing but `score`
+ * [B, D] is written).  cnf_logprob_fd_vjp is its backward:
+ *   pts_bar[i, :] = sum_d gbar[i, d] * d score[i, d] / d r_i      (may be NULL)
+ *   grad[p]      += sum_{i,d} gbar[i, d] * d score[i, d] / d params[p]
+ * (needs cnf_grad_enable; same config support as the other gradients). */
+int cnf_logprob_fd(CnfModel *m, const float *pts, const float *c,
+                   int64_t c_block, float dx, float *score, int64_t B,
+                   void *stream);
+int cnf_logprob_fd_vjp(CnfModel *m, const float *pts, const float *c,
+                       int64_t c_block, float dx, const float *gbar,
+                       float *pts_bar, float *grad, const float *params,
+                       int64_t B, void *stream);
+
 /* optax.adam(lr) update in place (solvers.py:55,95-96): b1 = 0.9, b2 = 0.999,
  * eps = 1e-8 are optax's defaults; `step` counts from 1. */
 int cnf_adam_step(float *params, const float *grad, float *mu, float *nu,
