@@ -312,8 +312,9 @@ __device__ __forceinline__ WgradPre wgrad_prefetch(const float* __restrict__ gw,
   p.o = wgrad_fetch(gw + o_wo, 16, gw + o_bo);
   p.h = wgrad_fetch(gw + o_w1, 16, gw + o_b1);
   p.f = wgrad_fetch(gw, d + 2, nullptr);
-  // pin the loads here: the compiler would sink them to their first use
-  asm volatile("" : "+v"(p.o.acc), "+v"(p.h.acc), "+v"(p.f.acc));
+  // keep the loads here (the scheduler would sink them to their first use) -- a scheduling barrier, not a use of
+  // the values: a use would make the wave wait for the loads on the spot
+  __builtin_amdgcn_sched_barrier(0);
   return p;
 }
 

@@ -20,6 +20,8 @@ def main(tag):
   stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
   if stats:
     shutil.copy(stats[0], os.path.join(dst, "kernel_stats.csv"))
+  if os.path.exists(os.path.join(src, "bench_line.json")):
+    shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, "bench_line.json"))
   out = {}
   for path in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -36,7 +38,7 @@ def main(tag):
   # FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of a
   # coalesced streaming read (checked here against the known algorithmic bytes).
   for kern, ctrs in out.items():
-    if "false" in kern and "FETCH_SIZE" in ctrs and "WRITE_SIZE" in ctrs and len(sys.argv) > 2:
+    if "flow_pwl_kernel" in kern and "false" in kern and "FETCH_SIZE" in ctrs and "WRITE_SIZE" in ctrs and len(sys.argv) > 2:
       spl = int(sys.argv[2])
       rd, wr = ctrs["FETCH_SIZE"]["mean"] * 1024 * 2, ctrs["WRITE_SIZE"]["mean"] * 1024
       with open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w") as f:
