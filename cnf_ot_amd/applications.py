@@ -118,6 +118,8 @@ def _kl_sum(ctx, T, cond, batch_size, source, coef):
 
 def _reverse_kl_sum(ctx, T, beta, cond, batch_size, coef):
   z, _, count = ctx.noise(batch_size)
+  if _use_unfused(ctx, z.shape[1]) and count <= UNFUSED_RKL_MAX_BATCH:
+    return _reverse_kl_unfused(ctx, T, beta, cond, batch_size, coef)
   return ctx.terms(_spec(_capi.TERM_REVERSE_KL, T=T, beta=beta), z, [cond], count, coef)
 
 
@@ -140,45 +142,50 @@ def _kinetic_sum(ctx, dt, conds, batch_size, coef):
 # 2*dim*B more points for the fast flow kernel, and the gradient comes from
 # torch.autograd over the differentiable flow passes (cnf_ot_amd.autograd).
 UNFUSED_SCORE_MIN_DIM = 6
+# ... and the reverse-KL term too while the rank's batch is small (the fused kernel runs one sample per lane:
+# 131 072 samples are 2 waves per SIMD)
+UNFUSED_RKL_MAX_BATCH = 131072
 
 
-def _score_terms_unfused(ctx, conds, batch_size, dt, dx, coef_score, loss_coef, drift=None):
-  """per-slice sums of  sum_d ((r2-r1)/dt + coef_score * score_d(r3) - drift_d(r3))^2  from three kinds of
-  launches: ONE base -> data pass over the 3 x S x count points (conditions t -+ dt/2 and t; at this size the
+def _score_terms_unfused(ctx, conds, batch_size, dt, dx, coef_score, loss_coef, drift=-1, a=0.0):
+  """per-slice sums of  sum_d ((r2-r1)/dt + coef_score * score_d(r3) - drift_d(r3))^2  from three launches:
+  ONE base -> data pass over the 3 x S x count points (conditions t -+ dt/2 and t; at this size the
   wave-per-dimension kernel), ONE central-difference score launch over the S x count points r3 (its 2 D
-  evaluation points per sample are generated inside the kernel), and a handful of elementwise torch ops; with
-  ctx.grad, back-propagated through cnf_pass_vjp / cnf_logprob_fd_vjp."""
-  from . import autograd as ag
+  evaluation points per sample exist only inside the kernel) and ONE epilogue (cnf_score_residual).  With ctx.grad
+  the epilogue also emits the adjoints, and two backward launches (cnf_logprob_fd_vjp, cnf_pass_vjp) accumulate
+  the parameter gradient -- the reverse sweep written out by hand: no autograd graph, a dozen host calls."""
   be = ctx.be
   z, _, count = ctx.noise(batch_size)
-  S, D = len(conds), z.shape[1]
+  S = len(conds)
   n = S * count
   t = torch.as_tensor(np.asarray(conds, dtype=np.float32), device=z.device)
-  flat = be._flat.detach().requires_grad_(ctx.grad is not None)
   tt = t.repeat_interleave(count)                             # per-sample condition
   z3 = z.repeat(3 * S, 1)                                     # the same draw for every slice and condition
   c3 = torch.cat([tt - 0.5 * dt, tt + 0.5 * dt, tt])
-  with torch.set_grad_enabled(ctx.grad is not None):
-    r, _ = ag.flow_forward(be, flat, z3, c3)
-    r1, r2, r3 = r[:n], r[n:2 * n], r[2 * n:]
-    score = ag.logprob_fd(be, flat, r3, tt, dx)
-    u = (r2 - r1) / dt + coef_score * score
-    if drift is not None:
-      u = u - drift(r3)
-    sums = (u.double() ** 2).reshape(S, count * D).sum(1)
-    if ctx.grad is not None:
-      (loss_coef * sums.sum()).backward()
-      ctx.grad += flat.grad
-  return sums.detach()
+  want = ctx.grad is not None
+  r, _ = be.forward_logdet(z3, c3, want_logdet=False)
+  r3 = r[2 * n:]
+  score = be.logprob_fd(r3, tt, dx)
+  sums, rbar, sbar = be.score_residual(r, score, count, dt, coef_score, drift, a, loss_coef, want)
+  if want:
+    r3bar = be.logprob_fd_vjp(r3, tt, dx, sbar, ctx.grad)     # adjoint of r3 through the score; + parameter gradient
+    rbar[2 * n:] += r3bar
+    be.pass_vjp(z3, c3, rbar, None, False, grad=ctx.grad, want_xbar=False)
+  return sums
 
 
-def _drift_torch(subtype, a):
-  if subtype == "ou":
-    return lambda r: -a * r
-  if subtype == "lorenz":
-    return lambda r: torch.stack([10 * (r[:, 1] - r[:, 0]), 9 * r[:, 0] * (28 / 9 - r[:, 2]) - r[:, 1],
-                                  9 * r[:, 0] * r[:, 1] - r[:, 2] * 8 / 3], dim=1)
-  raise ValueError(subtype)
+def _reverse_kl_unfused(ctx, T, beta, cond, batch_size, coef):
+  """reverse_kl_loss_fn from one base -> data launch + an epilogue (+ one backward launch): the form for
+  dimensions where a rank's share of the batch cannot fill the GPU from inside the fused kernel."""
+  be = ctx.be
+  z, _, count = ctx.noise(batch_size)
+  c = torch.tensor([cond], dtype=torch.float32, device=z.device)
+  y, lp = be.sample_logprob(z, c)
+  want = ctx.grad is not None
+  total, ybar, lpbar = be.rkl_residual(y, lp, cond, T, beta, coef, want)
+  if want:      # lp = base(noise) - fldj: the adjoint of the pass's log-det output is -lpbar
+    be.pass_vjp(z, c, ybar, -lpbar, False, grad=ctx.grad, want_xbar=False)
+  return total
 
 
 def _use_unfused(ctx, dim):
@@ -204,7 +211,7 @@ def _flow_matching_sum(ctx, dim, a, sigma, subtype, conds, batch_size, coef):
                      "use subtype='ou' for the documented drift -a*r in other dimensions")
   z, _, count = ctx.noise(batch_size)
   if _use_unfused(ctx, dim) and subtype in ("ou", "lorenz"):
-    return _score_terms_unfused(ctx, np.atleast_1d(conds), batch_size, 0.01, 0.01, sigma, coef, _drift_torch(subtype, a))
+    return _score_terms_unfused(ctx, np.atleast_1d(conds), batch_size, 0.01, 0.01, sigma, coef, _capi.DRIFTS[subtype], a)
   # dt and dx are overridden to 0.01 inside the reference function (:286,301)
   return ctx.terms(_spec(_capi.TERM_FLOW_MATCHING, subtype=_capi.DRIFTS[subtype], dt=0.01, dx=0.01,
                          coef=sigma, a=a), z, conds, count, coef)

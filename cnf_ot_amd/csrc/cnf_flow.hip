@@ -1069,10 +1069,12 @@ extern "C" int cnf_model_create(const CnfConfig* cfg, CnfModel** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, m->device) != hipSuccess) { delete m; return CNF_ERR_HIP; }
   m->num_cus = prop.multiProcessorCount;
-  // The MFMA conditioner is built and tested but NOT the default: fp32 MFMA and
-  // fp32 VALU do not overlap on gfx950 (their busy times add up: profiles/r01c),
-  // and at equal peak rate the packed-VALU conditioner is 4-5 % faster.
-  m->use_mfma = 0;
+  // The MFMA conditioner: fp32 MFMA and fp32 VALU do not overlap on gfx950 (their busy times add up:
+  // profiles/r01c), so at equal peak rate the packed-VALU conditioner is 4-5 % faster once the chip is full.  A
+  // launch of one wave per SIMD is a different regime: a lone wave issues one VALU instruction per 8 cycles
+  // (profiles/r01_issue_probe), and the MFMA form has ~45 % fewer of them and no scalar weight loads to wait
+  // for -- 6.1 vs 9.8 us per 65 536-sample call (profiles/r02_experiments/exp_latency.log).  2 = by launch size.
+  m->use_mfma = 2;
   m->use_pwl = 1;
   m->use_dpar = 1;
   // (D = 1 would need 2^32: encoded as 0, tile_load/tile_store take s = e)
@@ -1187,10 +1189,11 @@ extern "C" int cnf_model_set_fast_math(CnfModel* m, int on) {
   return CNF_OK;
 }
 
-/* Internal knob: 1 = MFMA conditioner where available, 0 = packed-VALU conditioner (default). */
-extern "C" int cnf_model_set_mfma(CnfModel* m, int on) {
-  if (!m) return CNF_ERR_INVALID;
-  m->use_mfma = on ? 1 : 0;
+/* Internal knob: 1 = MFMA conditioner wherever available, 0 = packed-VALU conditioner, 2 = MFMA for launches
+ * that leave the chip under-filled (default). */
+extern "C" int cnf_model_set_mfma(CnfModel* m, int mode) {
+  if (!m || mode < 0 || mode > 2) return CNF_ERR_INVALID;
+  m->use_mfma = mode;
   return CNF_OK;
 }
 
@@ -1262,7 +1265,7 @@ static int samples_per_lane(const CnfModel* m, int64_t B) {
 // = 1) while the one-sample-per-lane kernel would leave the chip under-filled.
 static int launch_flow_dpar(CnfModel* m, const FlowArgs& a, hipStream_t stream) {
   const int D = m->cfg.dim;
-  if (D < 3 || !m->fast_math || m->use_mfma || !m->use_dpar) return CNF_ERR_UNSUPPORTED;
+  if (D < 3 || !m->fast_math || m->use_mfma == 1 || !m->use_dpar) return CNF_ERR_UNSUPPORTED;
   // measured crossover with the one-sample-per-lane kernel (MI355X, D = 3 and D = 10, scripts/exp_dim10.py):
   // between 131 072 and 524 288 samples; 512 samples per CU
   if (m->use_dpar == 1 && a.B > (int64_t)m->num_cus * 512) return CNF_ERR_UNSUPPORTED;
@@ -1289,6 +1292,10 @@ static int launch_flow_dpar(CnfModel* m, const FlowArgs& a, hipStream_t stream) 
   return CNF_ERR_UNSUPPORTED;
 }
 
+#ifndef CNF_MFMA_SMALL_WAVES
+#define CNF_MFMA_SMALL_WAVES 1        /* waves of single-lane work per SIMD up to which use_mfma = 2 picks MFMA */
+#endif
+
 // LDS of the precise position path beyond the tile: the 2^(-i/32) table and the float64 `first` table
 static size_t precise_lds_bytes(int K) { return sizeof(double) * (size_t)(cnf::EXP2_N + hdr_floats(K)); }
 
@@ -1303,7 +1310,10 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
   const bool precise = PR && m->precise;
   const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * ts) * sizeof(float) +
                      (precise ? precise_lds_bytes(m->cfg.num_bins) + sizeof(float) * a.m.D * ts : 0);
-  if (m->fast_math && m->use_mfma && m->mfma_off > 0 && m->cfg.hidden_size == 16 && m->cfg.num_bins == 5) {
+  // launches below ~2 waves of single-lane work per SIMD: the MFMA conditioner (see cnf_model_create)
+  const bool small = a.B <= (int64_t)m->num_cus * 4 * 64 * CNF_MFMA_SMALL_WAVES;
+  if (m->fast_math && (m->use_mfma == 1 || (m->use_mfma == 2 && small)) && m->mfma_off > 0 &&
+      m->cfg.hidden_size == 16 && m->cfg.num_bins == 5) {
     if (!a.gate) m->last_path = CNF_PATH_MFMA;
     ProfScope ps(m, stream, false, a.B, CNF_PATH_MFMA);
     if (precise) {

@@ -582,6 +582,123 @@ __global__ void adam_kernel(float* __restrict__ params, const float* __restrict_
   params[i] -= lr * (m / bc1) / (sqrtf(v / bc2) + eps);
 }
 
+// ---------------------------------------------------------------------------
+// Epilogues of the UNFUSED loss terms (dim >= applications.UNFUSED_SCORE_MIN_DIM: the flow passes are separate,
+// chip-filling launches; these turn their outputs into per-slice sums and, for value_and_grad, into the adjoints
+// the backward launches start from).  One thread per sample.
+// ---------------------------------------------------------------------------
+struct ResidArgs {
+  const float* r;        // [3 n, D]: r1 (t - dt/2) | r2 (t + dt/2) | r3 (t)
+  const float* score;    // [n, D] central-difference score of log_prob at r3
+  float* rbar;           // [3 n, D] or null
+  float* sbar;           // [n, D] or null
+  double* sums;          // [n / count]
+  int64_t n, count;
+  int32_t D, subtype;    // subtype < 0: no drift (kinetic_with_score), else CnfDrift
+  float inv_dt, coef, a, loss_coef;
+};
+
+// sum_d ((r2 - r1)/dt + coef score_d - drift_d(r3))^2 per slice (applications.py:245-374) and its adjoints
+__global__ __launch_bounds__(256) void score_residual_kernel(const ResidArgs a) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int D = a.D;
+  float acc = 0.0f;
+  const bool valid = i < a.n;
+  if (valid) {
+    const float* r1 = a.r + i * D;
+    const float* r2 = a.r + (a.n + i) * D;
+    const float* r3 = a.r + (2 * a.n + i) * D;
+    const float* sc = a.score + i * D;
+    float x = r3[0], y = D > 1 ? r3[1] : 0.0f, z = D > 2 ? r3[2] : 0.0f;
+    float ub0 = 0.f, ub1 = 0.f, ub2 = 0.f;
+    for (int d = 0; d < D; ++d) {
+      float drift = 0.0f;
+      switch (a.subtype) {
+        case CNF_DRIFT_OU: drift = -a.a * r3[d]; break;
+        case CNF_DRIFT_SMILE: { const float q = x * x + y * y - 4.0f; drift = (d == 0 ? -q * x : -q * y - (y - 1.0f) * 2.0f) * a.a; break; }
+        case CNF_DRIFT_NONGRADIENT: drift = d == 0 ? x * -a.a - y * 0.5f : y * -a.a + x * 0.5f; break;
+        case CNF_DRIFT_LORENZ: drift = d == 0 ? (y - x) * 10.0f : (d == 1 ? x * 9.0f * (28.0f / 9.0f - z) - y : x * 9.0f * y - z * (8.0f / 3.0f)); break;
+        default: break;
+      }
+      const float u = fmaf(sc[d], a.coef, (r2[d] - r1[d]) * a.inv_dt) - drift;
+      acc = fmaf(u, u, acc);
+      if (a.rbar) {
+        const float ub = 2.0f * a.loss_coef * u;
+        a.rbar[i * D + d] = -ub * a.inv_dt;
+        a.rbar[(a.n + i) * D + d] = ub * a.inv_dt;
+        a.sbar[i * D + d] = a.coef * ub;
+        if (d == 0) ub0 = ub; else if (d == 1) ub1 = ub; else if (d == 2) ub2 = ub;
+        // r3_bar = -J_drift^T u_bar; the diagonal OU field is complete here, the coupled 2-D / 3-D fields below
+        a.rbar[(2 * a.n + i) * D + d] = a.subtype == CNF_DRIFT_OU ? a.a * ub : 0.0f;
+      }
+    }
+    if (a.rbar) {
+      float* r3b = a.rbar + (2 * a.n + i) * D;
+      if (a.subtype == CNF_DRIFT_SMILE) {
+        const float q = x * x + y * y - 4.0f;
+        r3b[0] = -(ub0 * (-a.a * (q + 2.0f * x * x)) + ub1 * (-a.a * 2.0f * x * y));
+        r3b[1] = -(ub0 * (-a.a * 2.0f * x * y) + ub1 * (-a.a * (q + 2.0f * y * y + 2.0f)));
+      } else if (a.subtype == CNF_DRIFT_NONGRADIENT) {
+        r3b[0] = -(ub0 * (-a.a) + ub1 * 0.5f);
+        r3b[1] = -(ub0 * (-0.5f) + ub1 * (-a.a));
+      } else if (a.subtype == CNF_DRIFT_LORENZ) {
+        r3b[0] = -(ub0 * -10.0f + ub1 * (28.0f - 9.0f * z) + ub2 * 9.0f * y);
+        r3b[1] = -(ub0 * 10.0f - ub1 + ub2 * 9.0f * x);
+        r3b[2] = -(ub1 * (-9.0f * x) + ub2 * (-8.0f / 3.0f));
+      }
+    }
+  }
+  // a wave whose samples share a slice: shuffle reduce, one double atomic; otherwise one atomic per sample
+  const int64_t slice = valid ? i / a.count : -1;
+  const int64_t s0 = __shfl(slice, 0, 64), s63 = __shfl(slice, 63, 64);
+  if (s0 == s63 && s0 >= 0) {
+    float part = acc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(a.sums + s0, (double)part);
+  } else if (valid) {
+    atomicAdd(a.sums + slice, (double)acc);
+  }
+}
+
+struct RklArgs {
+  const float* y;        // [n, D] samples
+  const float* lp;       // [n] their log_prob
+  float* ybar;           // [n, D] or null
+  float* lpbar;          // [n] or null
+  double* sums;          // [1]
+  int64_t n;
+  int32_t D;
+  float t, T, beta, loss_coef;
+};
+
+// sum_i log_prob_i - log(N(y_i; 0, vs I) ws + N(y_i; 0, vt I) wt)  (reverse_kl_loss_fn, applications.py:129-163)
+__global__ __launch_bounds__(256) void rkl_residual_kernel(const RklArgs a) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  float acc = 0.0f;
+  if (i < a.n) {
+    const int D = a.D;
+    float s2 = 0.0f;
+    for (int d = 0; d < D; ++d) { const float r = a.y[i * D + d]; s2 = fmaf(r, r, s2); }
+    const float vs = 2.0f / a.beta * (a.T + 1.0f), vt = 2.0f / a.beta;
+    const float ws = (a.T - a.t) / a.T, wt = a.t / a.T;
+    const float ls = -0.5f * D * logf(6.283185307179586f * vs), lt = -0.5f * D * logf(6.283185307179586f * vt);
+    const float as = -0.5f * s2 / vs + ls, at = -0.5f * s2 / vt + lt;
+    const float mx = fmaxf(as, at);
+    const float es = expf(as - mx) * ws, et = expf(at - mx) * wt;
+    acc = a.lp[i] - (mx + logf(es + et));
+    if (a.ybar) {
+      const float g = (es / vs + et / vt) / (es + et);      // -d logmix / d y_e = g * y_e
+      for (int d = 0; d < D; ++d) a.ybar[i * D + d] = a.loss_coef * g * a.y[i * D + d];
+      a.lpbar[i] = a.loss_coef;
+    }
+  }
+  float part = acc;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(a.sums, (double)part);
+}
+
 }  // namespace cnf
 
 using namespace cnf;
@@ -781,5 +898,38 @@ extern "C" int cnf_logprob_fd_vjp(CnfModel* m, const float* pts, const float* c,
   const int fb = (int)((m->n_params + 31) / 32);
   hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, n_slabs, m->n_params, params,
                      grad, (double)m->sc.span_eff, (double)m->sc.sp_offset);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+extern "C" int cnf_score_residual(const float* r, const float* score, int64_t n, int64_t count, int32_t D, float dt,
+                                  float coef, int32_t drift, float a_, float loss_coef, double* sums, float* rbar,
+                                  float* sbar, void* stream_) {
+  if (!r || !score || !sums || n < 0 || count < 1 || D < 1 || !(dt > 0.f) || (rbar == nullptr) != (sbar == nullptr))
+    return CNF_ERR_INVALID;
+  if (drift > CNF_DRIFT_LORENZ) return CNF_ERR_INVALID;
+  if ((drift == CNF_DRIFT_SMILE || drift == CNF_DRIFT_NONGRADIENT) && D != 2) return CNF_ERR_INVALID;
+  if (drift == CNF_DRIFT_LORENZ && D != 3) return CNF_ERR_INVALID;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t n_slices = (n + count - 1) / count;
+  if (n_slices == 0) return CNF_OK;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * (size_t)n_slices, stream) != hipSuccess) return CNF_ERR_HIP;
+  ResidArgs a;
+  a.r = r; a.score = score; a.rbar = rbar; a.sbar = sbar; a.sums = sums; a.n = n; a.count = count;
+  a.D = D; a.subtype = drift; a.inv_dt = 1.0f / dt; a.coef = coef; a.a = a_; a.loss_coef = loss_coef;
+  hipLaunchKernelGGL(score_residual_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+extern "C" int cnf_rkl_residual(const float* y, const float* lp, int64_t n, int32_t D, float t, float T, float beta,
+                                float loss_coef, double* sum, float* ybar, float* lpbar, void* stream_) {
+  if (!y || !lp || !sum || n < 0 || D < 1 || !(T > 0.f) || !(beta > 0.f) || (ybar == nullptr) != (lpbar == nullptr))
+    return CNF_ERR_INVALID;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (hipMemsetAsync(sum, 0, sizeof(double), stream) != hipSuccess) return CNF_ERR_HIP;
+  if (n == 0) return CNF_OK;
+  RklArgs a;
+  a.y = y; a.lp = lp; a.ybar = ybar; a.lpbar = lpbar; a.sums = sum; a.n = n; a.D = D;
+  a.t = t; a.T = T; a.beta = beta; a.loss_coef = loss_coef;
+  hipLaunchKernelGGL(rkl_residual_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }

@@ -152,10 +152,11 @@ class FlowEngine:
   def set_fast_math(self, on: bool) -> None:
     _capi.check(self.lib.cnf_model_set_fast_math(self._h, 1 if on else 0), "cnf_model_set_fast_math")
 
-  def set_mfma(self, on: bool) -> None:
-    """MFMA (v_mfma_f32_16x16x4_f32) conditioner where available (hidden 16,
-    5 bins, fast math), or the packed-VALU conditioner (the default)."""
-    _capi.check(self.lib.cnf_model_set_mfma(self._h, 1 if on else 0), "cnf_model_set_mfma")
+  def set_mfma(self, mode) -> None:
+    """MFMA (v_mfma_f32_16x16x4_f32) conditioner (hidden 16, 5 bins, fast
+    math): True / 1 = wherever available, False / 0 = packed-VALU conditioner,
+    2 = MFMA for launches that leave the chip under-filled (the default)."""
+    _capi.check(self.lib.cnf_model_set_mfma(self._h, int(mode)), "cnf_model_set_mfma")
 
   def set_pwl(self, mode: int) -> None:
     """Piecewise-linear conditioner tables (dim 2, slice-uniform condition):
@@ -418,6 +419,36 @@ class FlowEngine:
                                                 grad.data_ptr(), self._flat.data_ptr(), B,
                                                 _stream_ptr(self.device)), "cnf_logprob_fd_vjp")
     return pts_bar
+
+  def score_residual(self, r, score, count: int, dt: float, coef: float, drift: int, a: float,
+                     loss_coef: float = 0.0, want_adjoints: bool = False):
+    """cnf_score_residual: per-slice sums (float64 [n / count]) of the score-term residual from r [3n, D]
+    (samples at t -+ dt/2 and t) and score [n, D]; with want_adjoints also (rbar [3n, D], sbar [n, D])."""
+    n, D = score.shape
+    sums = torch.empty(-(-n // count), dtype=torch.float64, device=self.device)
+    rbar = torch.empty_like(r) if want_adjoints else None
+    sbar = torch.empty_like(score) if want_adjoints else None
+    with torch.cuda.device(self.device):
+      _capi.check(self.lib.cnf_score_residual(r.data_ptr(), score.data_ptr(), n, count, D, float(dt), float(coef),
+                                              int(drift), float(a), float(loss_coef), sums.data_ptr(),
+                                              rbar.data_ptr() if want_adjoints else None,
+                                              sbar.data_ptr() if want_adjoints else None,
+                                              _stream_ptr(self.device)), "cnf_score_residual")
+    return sums, rbar, sbar
+
+  def rkl_residual(self, y, lp, t: float, T: float, beta: float, loss_coef: float = 0.0, want_adjoints: bool = False):
+    """cnf_rkl_residual: sum_i lp_i - log mixture(y_i) (float64 [1]); with want_adjoints also (ybar, lpbar)."""
+    n, D = y.shape
+    total = torch.empty(1, dtype=torch.float64, device=self.device)
+    ybar = torch.empty_like(y) if want_adjoints else None
+    lpbar = torch.empty_like(lp) if want_adjoints else None
+    with torch.cuda.device(self.device):
+      _capi.check(self.lib.cnf_rkl_residual(y.data_ptr(), lp.data_ptr(), n, D, float(t), float(T), float(beta),
+                                            float(loss_coef), total.data_ptr(),
+                                            ybar.data_ptr() if want_adjoints else None,
+                                            lpbar.data_ptr() if want_adjoints else None,
+                                            _stream_ptr(self.device)), "cnf_rkl_residual")
+    return total, ybar, lpbar
 
   def jacobian(self, pts, cond, to_base=False) -> torch.Tensor:
     """[B, D, D] Jacobian d out_i / d in_j of a flow pass: D vector-Jacobian products."""

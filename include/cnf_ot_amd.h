@@ -310,6 +310,30 @@ int cnf_logprob_fd_vjp(CnfModel *m, const float *pts, const float *c,
                        float *pts_bar, float *grad, const float *params,
                        int64_t B, void *stream);
 
+/* Epilogues of loss terms composed from separate flow launches (what
+ * cnf_ot_amd.applications does from dim 6 up, where a rank's few samples cannot
+ * fill the GPU from inside one fused kernel).  Model-independent, like
+ * cnf_adam_step.
+ *
+ * cnf_score_residual: r [3n, D] = the samples at t - dt/2 | t + dt/2 | t (one
+ * base -> data launch), score [n, D] from cnf_logprob_fd; per slice of `count`
+ * samples  sums[s] = sum_{i,d} ((r2 - r1)/dt + coef score - drift_d(r3))^2
+ * (kinetic_with_score_loss_fn / flow_matching_loss_fn, applications.py:245-374;
+ * drift = CnfDrift, or -1 for none).  With rbar / sbar non-NULL it also writes
+ * the adjoints of r and score for d(loss) = loss_coef * d(sum of sums): the
+ * seeds of cnf_logprob_fd_vjp and cnf_pass_vjp.
+ *
+ * cnf_rkl_residual: y [n, D], lp [n] from cnf_sample_logprob;
+ * sum = sum_i lp_i - log(mixture(y_i)) of reverse_kl_loss_fn
+ * (applications.py:129-163), adjoints ybar / lpbar likewise. */
+int cnf_score_residual(const float *r, const float *score, int64_t n,
+                       int64_t count, int32_t D, float dt, float coef,
+                       int32_t drift, float a, float loss_coef, double *sums,
+                       float *rbar, float *sbar, void *stream);
+int cnf_rkl_residual(const float *y, const float *lp, int64_t n, int32_t D,
+                     float t, float T, float beta, float loss_coef, double *sum,
+                     float *ybar, float *lpbar, void *stream);
+
 /* optax.adam(lr) update in place (solvers.py:55,95-96): b1 = 0.9, b2 = 0.999,
  * eps = 1e-8 are optax's defaults; `step` counts from 1. */
 int cnf_adam_step(float *params, const float *grad, float *mu, float *nu,

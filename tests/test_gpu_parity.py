@@ -25,6 +25,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+MLP_PATHS = ("mlp1", "mlp2", "mfma")      # the kernels that evaluate the conditioner MLP (mfma: small launches)
 TOL_Y = 2e-5
 TOL_LD = 1e-5
 TOL_LP_SAMPLE = 1e-5
@@ -347,7 +348,7 @@ def test_entry_points_are_graph_capturable(dev):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=side):
       eng.sample_logprob(x, t, out=y, logp_out=lp)
-      assert eng.last_path() == ("tables" if mode == 2 else "mlp1")
+      assert eng.last_path() == ("tables" if mode == 2 else "mfma")       # 16 384 samples: the small-launch kernel
     x.copy_(eng.normal(2 + mode, S * Bs))                      # new inputs in the captured buffers
     t.copy_(torch.linspace(0.3, 0.9, S, device=dev))
     graph.replay()
@@ -380,7 +381,7 @@ def test_compute_calls_never_allocate(dev):
   graph = torch.cuda.CUDAGraph()
   with torch.cuda.graph(graph, stream=side):                   # FlowEngine.reserve is a no-op while capturing
     eng.sample_logprob(x, t, out=y, logp_out=lp)
-    assert eng.last_path() in ("mlp1", "mlp2")
+    assert eng.last_path() in MLP_PATHS
   assert eng.lib.cnf_model_reserved(eng._h, side.cuda_stream) == 0
   graph.replay()
   torch.cuda.synchronize()
@@ -429,13 +430,13 @@ def test_per_sample_uniform_condition_is_detected_on_device(dev):
     assert eng.last_path() == "detect"
     eng.set_pwl(0)
     ref_mlp = call(c_mix)
-    assert eng.last_path() in ("mlp1", "mlp2")
+    assert eng.last_path() in MLP_PATHS
     eng.set_pwl(1)
     for a, b in zip(got, ref_mlp):
       assert torch.equal(a, b), fn
   # a single 65 536-sample batch stays on the MLP kernel (the tables do not pay there): no check is enqueued
   eng.sample_logprob(x[:65536], c_uni[:65536])
-  assert eng.last_path() in ("mlp1", "mlp2")
+  assert eng.last_path() in MLP_PATHS
 
 
 def test_table_path_many_slices(dev):
@@ -523,7 +524,7 @@ def test_wave_per_dimension_kernel(dev, D, B):
     y_ref, lp_ref = oracle.sample_logprob(ocfg, params, noise.astype(np.float64), c_host)     # c of length B: per sample
     eng.set_dpar(0)
     y0, lp0 = eng.sample_logprob(_t(noise, dev), cond)
-    assert eng.last_path() in ("mlp1", "mlp2")
+    assert eng.last_path() in MLP_PATHS
     eng.set_dpar(2)
     for spl in (1, 2):
       eng.set_samples_per_lane(spl)

@@ -171,3 +171,26 @@ def test_losses_at_identity_flow(oracle_lib):
   comp = np.arange(B) % 8
   kl_T = ol.kl_loss_fn(flow, 1.0, 1.0, z, "mixture", comp)
   assert abs(kl_T - (0.5 * (z ** 2).sum(1) + np.log(2 * np.pi)).mean()) < 1e-12
+
+
+def test_reference_vectors_if_present(oracle_lib, golden_dir):
+  """The one missing pin: outputs of the reference itself, exported on a box that has JAX by
+  scripts/export_reference_vectors.py (parameters by haiku name, float64).  None can be produced in the build
+  container (jax / distrax / haiku are not installed), so this test SKIPS until such files are dropped into
+  tests/golden/ -- and from then on pins the oracle's absolute values to 1e-9."""
+  import glob
+  files = sorted(glob.glob(os.path.join(golden_dir, "reference_d*.npz")))
+  if not files:
+    pytest.skip("no reference-exported vectors (parity unpinned: jax is not installable here)")
+  from cnf_ot_amd.params import FlowConfig, from_tree
+  for f in files:
+    g = np.load(f, allow_pickle=False)
+    D = g["x"].shape[1]
+    cfg = oracle.OracleConfig(D=D)
+    tree = {k: g[k] for k in g.files if "/" in k}
+    params = from_tree(FlowConfig(dim=D), tree).flat.double().numpy()
+    y, _ = oracle.forward_logdet(cfg, params, g["x"], g["c"])
+    assert np.abs(y - g["y"]).max() <= 1e-9
+    assert np.abs(oracle.log_prob(cfg, params, g["y"], g["c"]) - g["log_prob_y"]).max() <= 1e-9
+    xb, _ = oracle.inverse_logdet(cfg, params, g["y"], g["c"])
+    assert np.abs(xb - g["x_back"]).max() <= 1e-9
