@@ -55,6 +55,7 @@ def build(force: bool = False, minimal: bool = False, verbose: bool = False) -> 
          "-Wall", "-Wno-unused-function"]
   if minimal:
     cmd.append("-DCNF_MINIMAL_CONFIGS")
+  cmd += os.environ.get("CNF_EXTRA_FLAGS", "").split()      # experiment switches (scripts/): never set by the product
   cmd += [os.path.join(SRC_DIR, s) for s in SOURCES]
   tmp = LIB_PATH + ".tmp"
   cmd += ["-o", tmp]

@@ -64,6 +64,10 @@ enum TabField {
   F_XK,      // x knots [K+1]
   F_YK,      // y knots [K+1]
   F_TAIL,    // d_lo, d_hi, log d_lo, log d_hi, 1/d_lo, 1/d_hi
+  F_XKB,     // -2^60 x x knot j, each stored TWICE ([2 j], [2 j + 1]): a scalar-register pair operand of the
+  F_XKB2,    //   packed clamp-FMA that forms the bin masks of a sample pair (bin_of_scaled); two fields wide
+  F_YKB,     // the same for the y knots
+  F_YKB2,
   F_COUNT
 };
 enum { T_DLO = 0, T_DHI, T_LOG_DLO, T_LOG_DHI, T_INV_DLO, T_INV_DHI };
@@ -283,18 +287,38 @@ template <int K, class R> __device__ __forceinline__ int bin_of(const R* pos, R 
   for (int j = 1; j < K; ++j) k += (v >= pos[j]) ? 1 : 0;
   return k;
 }
-// Two samples: the sign bits of (knot - v), one packed subtract per knot for
-// both samples (v exactly on a knot lands in the lower bin; the spline is
-// continuous there).
+// Two samples: 0/1 masks [v > knot_j] from ONE packed FMA with the clamp modifier per knot,
+// clamp(v 2^60 - knot_j 2^60) (a single rounding: the sign is that of v - knot_j), summed in fp32 and converted
+// once (v exactly on a knot lands in the lower bin; the spline is continuous there).  11 instructions per pair
+// instead of 26 for per-sample sign-bit arithmetic.
+__device__ __forceinline__ v2f step_fma(v2f v, v2f big, v2f neg_knot_big) {
+  v2f m;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m) : "v"(v), "v"(big), "v"(neg_knot_big));
+  return m;
+}
 template <int K> __device__ __forceinline__ v2i bin_of(const float* pos, v2f v) {
-  uint32_t kx = 0, ky = 0;
+  const v2f big = v2f{1.152921504606846976e18f, 1.152921504606846976e18f};       // 2^60
+  v2f c = v2f{0.0f, 0.0f};
 #pragma unroll
   for (int j = 1; j < K; ++j) {
-    const v2f t = splat<v2f>(pos[j]) - v;
-    kx += __float_as_uint(t.x) >> 31;
-    ky += __float_as_uint(t.y) >> 31;
+    const float nk = pos[j] * -1.152921504606846976e18f;
+    c += step_fma(v, big, v2f{nk, nk});
   }
-  return v2i{(int)kx, (int)ky};
+  return v2i{(int)c.x, (int)c.y};
+}
+// The same with the knots pre-scaled by -2^60 and duplicated in the prepared table (F_XKB / F_YKB), read through
+// the scalar cache: the mask of knot j is ONE instruction, v_pk_fma_f32 v, 2^60, s[pair] clamp.
+template <int K> __device__ __forceinline__ v2i bin_of_scaled(uniform_ptr kb, v2f v) {
+  const v2f big = v2f{1.152921504606846976e18f, 1.152921504606846976e18f};       // 2^60
+  v2f c = v2f{0.0f, 0.0f};
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+    const v2f nk = v2f{kb[2 * j], kb[2 * j + 1]};
+    v2f m;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m) : "v"(v), "v"(big), "s"(nk));
+    c += m;
+  }
+  return v2i{(int)c.x, (int)c.y};
 }
 template <int K, class R> __device__ __forceinline__ R gather(const R* tab, int f, int k) {
   return tab[tab_off(f, K) + k];
@@ -324,12 +348,20 @@ template <> struct BinRow<v2f> {
   template <int K> __device__ __forceinline__ v2f get(int f) const { return v2f{px[tab_off(f, K)], py[tab_off(f, K)]}; }
 };
 
+// `gprep` (sample pairs only): the prepared table in GLOBAL memory, for the scalar-operand bin masks
 template <int K, bool INV, bool FAST, class T>
 __device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab, T v,
-                                             const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld) {
+                                             const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld,
+                                             const float* gprep = nullptr) {
   typedef typename Lanes<T>::real R;
   const R* pos = tab + tab_off(INV ? F_YK : F_XK, K);
-  const typename Lanes<T>::index k = bin_of<K>(pos, v);
+  typename Lanes<T>::index k;
+  if constexpr (std::is_same<T, v2f>::value) {
+    if (gprep) k = bin_of_scaled<K>(as_uniform(gprep + tab_off(INV ? F_YKB : F_XKB, K)), v);
+    else k = bin_of<K>(pos, v);
+  } else {
+    k = bin_of<K>(pos, v);
+  }
   const BinRow<T> row(tab, k);
   rqs_bin_eval<INV, FAST, T>(v, row.template get<K>(F_X0), row.template get<K>(F_Y0), row.template get<K>(F_BW),
                              row.template get<K>(F_BH), row.template get<K>(F_IBW),
@@ -362,29 +394,43 @@ __device__ __forceinline__ v2f step_mask(v2f d, v2f big) {
   return m;
 }
 
-// cond_spline for sample pairs fed from the piecewise-linear tables: rows hold
-// the softmax logits in log2 units and the slope logits with the softplus
-// offset added.  The bin is selected arithmetically with 0/1 masks m_k =
-// [v > knot_k] in packed FMAs (40 packed instructions per pair instead of 8
-// compares + 48 v_cndmask):
+// cond_spline for sample pairs fed from the piecewise-linear tables.  Rows hold the softmax logits in log2 units,
+// shifted per piece so that each group's maximum is ~0 near the samples the piece serves, and the slope logits
+// with the softplus offset added, also in log2 units (cnf_pwl.h).  The bin is selected arithmetically with 0/1 masks m_k = [v > knot_k]
+// in packed FMAs (40 packed instructions per pair instead of 8 compares + 48 v_cndmask):
 //   x0 = lo + sum m_k w_(k-1)  (bitwise the running knot),
 //   bw, bh, t0, t1 = sum o_k (w_k, h_k, t_k, t_(k+1))  with the one-hot o_k = m_k - m_(k+1)
 // -- products with 0 or 1 and sums of zeros: bitwise the selected values.
-template <int K, bool INV, bool FAST>
+// SHIFT_FREE (the table builder has checked the sample's cell: each group's maximum within +-4 of zero, slope
+// logits in [-3, 40]): e_k = 2^th_k directly -- no running maximum, no subtraction; ONE reciprocal for both
+// softmax sums; slopes as ln2 log2(1 + 2^t) with no small-argument series.
+// Otherwise the general form: running maximum, the log1p series for slope arguments near zero.
+template <int K, bool INV, bool FAST, bool SHIFT_FREE>
 __device__ __forceinline__ void cond_spline_masked(const v2f (&th)[3 * K + 1], v2f v,
                                                    const SplineConsts& sc, v2f& out, v2f& ld) {
   using M = Math<FAST>;
   typedef v2f T;
-  T mw = th[0], mh = th[K];
-#pragma unroll
-  for (int k = 1; k < K; ++k) { mw = vmax(mw, th[k]); mh = vmax(mh, th[K + k]); }
   T ew[K], eh[K];
+  T aw, ah;
+  if constexpr (SHIFT_FREE) {
 #pragma unroll
-  for (int k = 0; k < K; ++k) { ew[k] = M::exp2(th[k] - mw); eh[k] = M::exp2(th[K + k] - mh); }
-  T sw = ew[0], sh = eh[0];
+    for (int k = 0; k < K; ++k) { ew[k] = M::exp2(th[k]); eh[k] = M::exp2(th[K + k]); }
+    T sw = ew[0] + ew[1], sh = eh[0] + eh[1];
 #pragma unroll
-  for (int k = 1; k < K; ++k) { sw += ew[k]; sh += eh[k]; }
-  const T aw = M::rcp(sw) * sc.span_eff, ah = M::rcp(sh) * sc.span_eff;
+    for (int k = 2; k < K; ++k) { sw += ew[k]; sh += eh[k]; }
+    const T r = M::rcp(sw * sh) * sc.span_eff;
+    aw = r * sh; ah = r * sw;
+  } else {
+    T mw = th[0], mh = th[K];
+#pragma unroll
+    for (int k = 1; k < K; ++k) { mw = vmax(mw, th[k]); mh = vmax(mh, th[K + k]); }
+#pragma unroll
+    for (int k = 0; k < K; ++k) { ew[k] = M::exp2(th[k] - mw); eh[k] = M::exp2(th[K + k] - mh); }
+    T sw = ew[0], sh = eh[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) { sw += ew[k]; sh += eh[k]; }
+    aw = M::rcp(sw) * sc.span_eff; ah = M::rcp(sh) * sc.span_eff;
+  }
   const T big = splat<T>(1.152921504606846976e18f);       // 2^60
   T px = splat<T>(sc.lo), py = splat<T>(sc.lo);            // running knot k
   T wp = vfma(ew[0], aw, splat<T>(sc.min_bin)), hp = vfma(eh[0], ah, splat<T>(sc.min_bin));   // bin k-1
@@ -410,7 +456,21 @@ __device__ __forceinline__ void cond_spline_masked(const v2f (&th)[3 * K + 1], v
   bh = vfma(mprev, hp, bh);
   t0 = vfma(mprev, th[3 * K - 1], t0);
   t1 = vfma(mprev, th[3 * K], t1);
-  const T d0 = knot_slope<FAST, T, true>(t0, sc), d1 = knot_slope<FAST, T, true>(t1, sc);
+  T d0, d1;
+  if constexpr (SHIFT_FREE) {      // softplus(t) + m = ln2 log2(1 + 2^(t log2 e)) + m, t in [-3, 40]
+    const T l0 = v2f{__builtin_amdgcn_logf(M::exp2(t0).x + 1.0f), __builtin_amdgcn_logf(M::exp2(t0).y + 1.0f)};
+    const T l1 = v2f{__builtin_amdgcn_logf(M::exp2(t1).x + 1.0f), __builtin_amdgcn_logf(M::exp2(t1).y + 1.0f)};
+    d0 = vfma(l0, splat<T>(LN2), splat<T>(sc.min_slope));
+    d1 = vfma(l1, splat<T>(LN2), splat<T>(sc.min_slope));
+  } else {
+    // natural units.  The product must be ROUNDED before knot_slope forms v + |v|: contracted into an FMA,
+    // t LN2 + |round(t LN2)| is the product's rounding error instead of 0, and a slope at its floor of 1e-4 is
+    // then off by up to ulp(|t|) -- found by the soak (scripts/soak_pwl.py), tails with |u| >> 16.
+    T n0 = t0 * LN2, n1 = t1 * LN2;
+    asm volatile("" : "+v"(n0), "+v"(n1));
+    d0 = knot_slope<FAST, T, true>(n0, sc);
+    d1 = knot_slope<FAST, T, true>(n1, sc);
+  }
   const T ibw = M::rcp(bw);
   const T s = bh * ibw;
   const T st = d1 + d0 - s * 2.0f;
@@ -617,6 +677,10 @@ __device__ __forceinline__ void cond_spline_precise(const float (&th)[3 * K + 1]
   const double base_k = fma((double)kk, pc.min_bin, pc.lo);
   const double x0 = fma(aw, Sw_sel, base_k), y0 = fma(ah, Sh_sel, base_k);
   const double bw = fma(aw, ew_sel, pc.min_bin), bh = fma(ah, eh_sel, pc.min_bin);
+  if (LOG2_UNITS) {          // table rows carry (t + offset) log2 e; rounded product (see cond_spline_masked)
+    t0 *= LN2; t1 *= LN2;
+    asm volatile("" : "+v"(t0), "+v"(t1));
+  }
   const float d0 = knot_slope<FAST, float, LOG2_UNITS>(t0, sc), d1 = knot_slope<FAST, float, LOG2_UNITS>(t1, sc);
   rqs_fwd_bin_f64<FAST>(v, v_lo, x0, y0, bw, bh, d0, d1, out, out_lo, ld);
   if (maybe_outside(v, sc.lo, sc.hi)) {      // linear tails: bin 0 / bin K-1 were selected

@@ -146,6 +146,11 @@ __global__ void prepare_kernel(const float* __restrict__ params, float* __restri
     prep[tab_off(F_L2S, K) + k] = (float)(2.0 * log(s));
   }
   for (int k = 0; k <= K; ++k) {
+    const float big = 1.152921504606846976e18f;      // 2^60
+    if (2 * k + 1 < 2 * tab_stride(K)) {
+      prep[tab_off(F_XKB, K) + 2 * k] = prep[tab_off(F_XKB, K) + 2 * k + 1] = -(float)xk[k] * big;
+      prep[tab_off(F_YKB, K) + 2 * k] = prep[tab_off(F_YKB, K) + 2 * k + 1] = -(float)yk[k] * big;
+    }
     prep[tab_off(F_XK, K) + k] = (float)xk[k];
     prep[tab_off(F_YK, K) + k] = (float)yk[k];
     td[tab_off(F_XK, K) + k] = xk[k];
@@ -538,11 +543,14 @@ __device__ __forceinline__ void pwl_stage(float* tbl, const float* __restrict__ 
 // The dim-2 flow on one sample pair held in registers, conditioner from the tables (`tbl`: the L
 // tables in LDS, `gtbl`: the same in global memory for rows past the LDS window).  In place;
 // returns the accumulated log|det J| of the direction.
-template <int K, bool TO_BASE, bool FAST, bool PRECISE = false>
+// SHIFT_FREE_OK: use the shift-free spline evaluation where the sample's grid cell allows it (the flow kernels;
+// the loss kernel, at its register limit with three table sets, always evaluates the general form).
+template <int K, bool TO_BASE, bool FAST, bool PRECISE = false, bool SHIFT_FREE_OK = false>
 __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, const float* __restrict__ gtbl,
                                             int L, const SplineConsts& sc, v2f& u0, v2f& u1,
                                             const PreciseConsts* pc = nullptr, const double* e2tab = nullptr,
-                                            const double* tabd = nullptr, BaseAcc<v2f>* bacc = nullptr) {
+                                            const double* tabd = nullptr, BaseAcc<v2f>* bacc = nullptr,
+                                            const float* gprep = nullptr) {
   constexpr bool INV = !TO_BASE;
   static_assert(!PRECISE || TO_BASE, "precise path: data -> base");
   v2f acc = splat<v2f>(0.0f);
@@ -556,18 +564,25 @@ __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, 
       table_spline_precise<K, FAST>(tab, tabd, uf, odd ? lo1 : lo0, sc, of, ld, olo_f);
       if (step == L - 1) bacc->add(of, olo_f);
     } else {
-      table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld);
+      table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld, gprep);
     }
     acc += ld;
     v2f th[PWL_P];
-    pwl_eval(tbl + l * PWL_LTBL, gtbl + (int64_t)l * PWL_TBL, TO_BASE ? of : uf, th);
+    bool general;
+    pwl_eval(tbl + l * PWL_LTBL, gtbl + (int64_t)l * PWL_TBL, TO_BASE ? of : uf, th, general);
     if constexpr (PRECISE) {
       cond_spline_precise<K, FAST, true>(th, uo, odd ? lo0 : lo1, sc, *pc, e2tab, oo, ld, olo_o);
       if (step == L - 1) bacc->add(oo, olo_o);
       lo0 = odd ? olo_o : olo_f;
       lo1 = odd ? olo_f : olo_o;
+#ifdef CNF_PWL_FORCE_GENERAL        /* experiment switch: never the shift-free form */
+    } else if (true) {
+#else
+    } else if (!SHIFT_FREE_OK || __builtin_amdgcn_ballot_w64(general) != 0) {      // wave-uniform: a lane's cell is marked
+#endif
+      cond_spline_masked<K, INV, FAST, false>(th, uo, sc, oo, ld);
     } else {
-      cond_spline_masked<K, INV, FAST>(th, uo, sc, oo, ld);
+      cond_spline_masked<K, INV, FAST, true>(th, uo, sc, oo, ld);
     }
     acc += ld;
     u0 = odd ? oo : of;
@@ -623,8 +638,8 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
     v2f base = splat<v2f>(0.0f);
     if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = (u0 * u0 + u1 * u1) * -0.5f - (float)(2 * HALF_LOG_2PI);
     BaseAcc<v2f> bacc;
-    const v2f acc = flow2_tables<K, TO_BASE, FAST, PRECISE>(tab, tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, sc,
-                                                            u0, u1, &a.m.scd, e2tab, tabd, &bacc);
+    const v2f acc = flow2_tables<K, TO_BASE, FAST, PRECISE, true>(tab, tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, sc,
+                                                            u0, u1, &a.m.scd, e2tab, tabd, &bacc, a.m.prep);
     if (a.aux) {
       v2f r = acc;
       if constexpr (PRECISE) { if (a.aux_mode == AUX_LOGPROB) r = bacc.log_prob(acc, 2); }
@@ -1248,10 +1263,17 @@ extern "C" int cnf_model_set_params(CnfModel* m, const float* params, void* stre
 }
 
 
+#ifndef CNF_MFMA_SMALL_WAVES
+#define CNF_MFMA_SMALL_WAVES 4        /* waves of single-lane work per SIMD up to which use_mfma = 2 picks MFMA */
+#endif
+
 // Two samples per lane (packed fp32) once the batch fills every SIMD with at
 // least one wave of sample pairs; one sample per lane below that.
 static int samples_per_lane(const CnfModel* m, int64_t B) {
   if (m->force_spl == 1 || m->force_spl == 2) return m->force_spl;
+  // the small-launch regime of the MFMA conditioner (launch_flow) is one sample per lane
+  if (m->use_mfma == 2 && m->mfma_off > 0 && m->cfg.hidden_size == 16 && m->cfg.num_bins == 5 &&
+      B <= (int64_t)m->num_cus * 4 * 64 * CNF_MFMA_SMALL_WAVES) return 1;
   return (m->fast_math && B >= (int64_t)m->num_cus * 4 * 64 * 2) ? 2 : 1;
 }
 
@@ -1292,10 +1314,6 @@ static int launch_flow_dpar(CnfModel* m, const FlowArgs& a, hipStream_t stream) 
   return CNF_ERR_UNSUPPORTED;
 }
 
-#ifndef CNF_MFMA_SMALL_WAVES
-#define CNF_MFMA_SMALL_WAVES 1        /* waves of single-lane work per SIMD up to which use_mfma = 2 picks MFMA */
-#endif
-
 // LDS of the precise position path beyond the tile: the 2^(-i/32) table and the float64 `first` table
 static size_t precise_lds_bytes(int K) { return sizeof(double) * (size_t)(cnf::EXP2_N + hdr_floats(K)); }
 
@@ -1310,7 +1328,8 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
   const bool precise = PR && m->precise;
   const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * ts) * sizeof(float) +
                      (precise ? precise_lds_bytes(m->cfg.num_bins) + sizeof(float) * a.m.D * ts : 0);
-  // launches below ~2 waves of single-lane work per SIMD: the MFMA conditioner (see cnf_model_create)
+  // launches of up to 4 waves of single-lane work per SIMD: the MFMA conditioner, one sample per lane (measured
+  // crossover with the packed-VALU kernel, dim 2 and dim 10: profiles/r02_experiments/exp_latency.log)
   const bool small = a.B <= (int64_t)m->num_cus * 4 * 64 * CNF_MFMA_SMALL_WAVES;
   if (m->fast_math && (m->use_mfma == 1 || (m->use_mfma == 2 && small)) && m->mfma_off > 0 &&
       m->cfg.hidden_size == 16 && m->cfg.num_bins == 5) {

@@ -48,11 +48,24 @@ constexpr int PWL_LTBL = PWL_OFF_PIECE + PWL_LROWS * PWL_ROW;
 constexpr int PWL_N_SLOT = PWL_NBP - 1;   // the piece count n, stored (as int bits) in the last padding slot of bp[]
 
 
-// One block (512 threads) per (slice, layer).  Rows are written pre-scaled for the spline that
-// consumes them (cond_spline_masked): the 2K softmax logits in log2 units (x log2 e), the K + 1 slope
-// logits with the softplus offset added.  Rows past
-// the last piece are never read (the search stops at the +inf padding) and are left unwritten.
+// One block (512 threads) per (slice, layer).  Rows are written in the form the spline that consumes them
+// (cond_spline_masked) wants:
+//   m = 0..4, 5..9   softmax logits in log2 units, SHIFTED by a per-piece constant per group: the group's largest
+//                    logit at the piece's centre is 0 (softmax is shift-invariant).  Where the group maximum
+//                    stays within +-PWL_FAST_LOGIT of 0 over the piece, the per-sample running maximum and its
+//                    subtraction are not needed: e_k = 2^th_k directly, with the dominant terms' exponents small
+//                    (full fp32 accuracy) and no overflow;
+//   m = 10..15       slope logits with the softplus offset added, in log2 units.
+// The shift-free evaluation is only safe (and only accurate) under those bounds and with the slope logits in
+// [PWL_FAST_SLOPE_LO, PWL_FAST_SLOPE_HI] (natural units): the kernel checks this HERE, per piece over the part of
+// the piece inside the search grid, and marks every grid cell that touches a piece outside the bounds (and the
+// two outermost cells, which also catch every u beyond the grid) with the sign bit of its entry: a wave that
+// sees a marked cell evaluates the spline the general way (running maximum, log1p series for tiny slopes).
+// Rows past the last piece are never read (the search stops at the +inf padding) and are left unwritten.
 // `c_offset` is added to the slice's condition (the loss kernels need t - dt/2 and t + dt/2).
+constexpr double PWL_FAST_LOGIT = 4.0;           // log2 units: the group maximum stays in [-4, 4] over the piece
+constexpr double PWL_FAST_SLOPE_LO = -3.0;       // below: log(1 + e^v) in fp32 loses the slope's relative accuracy
+constexpr double PWL_FAST_SLOPE_HI = 40.0;
 constexpr int PWL_CHUNK = 64;             // pieces per pass of the two-stage affine-map computation
 
 __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict__ weights /* prep + hdr */,
@@ -63,6 +76,10 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
   __shared__ double bpu[PWL_H], sbp[PWL_H];
   __shared__ double candu[PWL_NPIECE - 1], cand[PWL_NPIECE - 1];
   __shared__ double PQ[PWL_CHUNK * PWL_H * 2];
+  __shared__ double RAW[PWL_CHUNK * PWL_P * 2];     // (S, T about u_ref) of every output of the chunk's pieces
+  __shared__ int bad[PWL_NPIECE];                  // piece needs the general spline evaluation
+  __shared__ double urefs[PWL_CHUNK];
+  __shared__ int icnt[17], ioff[17];               // finite roots per first-layer interval, and their prefix sums
   const int tid = threadIdx.x;
   const int slice = blockIdx.x / L, l = blockIdx.x % L;
   const float* w = weights + l * per_layer;         // D = 2: the layer's only conditioner (d = 1)
@@ -95,16 +112,15 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
     return fl && fh ? 0.5 * (lo + hi) : (fl ? lo + 1.0 : (fh ? hi - 1.0 : 0.0));
   };
   // second-layer zero crossings inside each of the 17 first-layer intervals
-  if (tid < PWL_H) candu[tid] = sbp[tid];
+  double root = INF;
+  const int iv = tid / PWL_H, kk = tid % PWL_H;        // interval, second-layer unit (tid < 17 * 16)
   if (tid < 17 * PWL_H) {
-    const int i = tid / PWL_H, k = tid % PWL_H;
-    const double lo = i == 0 ? -INF : sbp[i - 1], hi = i == PWL_H ? INF : sbp[i];
-    double root = INF;
+    const double lo = iv == 0 ? -INF : sbp[iv - 1], hi = iv == PWL_H ? INF : sbp[iv];
     if (lo < hi && lo < INF) {
       const double u = test_point(lo, hi);
-      double P = 0.0, Q = bb1[k];
+      double P = 0.0, Q = bb1[kk];
       for (int j = 0; j < PWL_H; ++j) {
-        const double on = a1[j] * u + b1v[j] > 0.0 ? W1[j * PWL_H + k] : 0.0;
+        const double on = a1[j] * u + b1v[j] > 0.0 ? W1[j * PWL_H + kk] : 0.0;
         P += on * a1[j];
         Q += on * b1v[j];
       }
@@ -112,28 +128,38 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
     }
     candu[PWL_H + tid] = root;
   }
+  for (int p = tid; p < PWL_NPIECE - 1; p += blockDim.x) cand[p] = INF;
+  for (int p = tid; p < PWL_NPIECE; p += blockDim.x) bad[p] = 0;
   __syncthreads();
-  // rank sort of the 288 candidates (+inf = none), ties by index
-  double mine = INF;
-  if (tid < PWL_NPIECE - 1) {
-    mine = candu[tid];
-    int r = 0;
-    for (int j = 0; j < PWL_NPIECE - 1; ++j) { const double o = candu[j]; r += (o < mine || (o == mine && j < tid)) ? 1 : 0; }
-    cand[r] = mine;
+  // Sorted order without a 288 x 288 rank sort: the roots of interval i lie strictly between the sorted
+  // first-layer breakpoints sbp[i-1] and sbp[i], so the sorted sequence is, interval by interval, the interval's
+  // roots (ranked among the <= 16 of them: 16 comparisons, ties by unit) followed by sbp[i].
+  int rank_in = 0;
+  if (tid < 17 * PWL_H) {
+    int cnt = 0;
+    for (int j = 0; j < PWL_H; ++j) {
+      const double o = candu[PWL_H + iv * PWL_H + j];
+      rank_in += (o < root || (o == root && j < kk)) ? 1 : 0;
+      cnt += o < INF ? 1 : 0;
+    }
+    if (kk == 0) icnt[iv] = cnt;
   }
-  const int n = __syncthreads_count(mine < INF);      // finite breakpoints; pieces 0 .. n
+  __syncthreads();
+  if (tid < 17) {                                   // roots before interval tid
+    int sum = 0;
+    for (int i = 0; i < tid; ++i) sum += icnt[i];
+    ioff[tid] = sum;
+  }
+  __syncthreads();
+  if (tid < 17 * PWL_H && root < INF) cand[iv + ioff[iv] + rank_in] = root;       // iv first-layer breakpoints precede it
+  if (tid < PWL_H && sbp[tid] < INF) cand[tid + ioff[tid] + icnt[tid]] = sbp[tid];
+  int n1 = 0;
+  for (int j = 0; j < PWL_H; ++j) n1 += sbp[j] < INF ? 1 : 0;
+  const int n = n1 + ioff[16] + icnt[16];             // finite breakpoints; pieces 0 .. n
+  __syncthreads();
   float* T = tables + (int64_t)blockIdx.x * PWL_TBL;
   for (int p = tid; p < PWL_NBP; p += blockDim.x)
     T[p] = p == PWL_N_SLOT ? __int_as_float(n) : (p < n ? (float)cand[p] : __int_as_float(0x7f800000));
-  // coarse grid: number of breakpoints <= the cell's left edge (a lower bound for the scan).  The edge is
-  // pulled in by 1e-4: pwl_cell() computes the cell in fp32, and u a rounding error below an edge may land
-  // in the cell above it.
-  for (int g = tid; g < PWL_NG; g += blockDim.x) {
-    const double x = (double)PWL_GMIN + (double)g / (double)PWL_GSCALE - 1e-4;
-    int lo_ = 0, hi_ = g == 0 ? 0 : n;          // cell 0 also serves every u below the grid: scan from piece 0
-    while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (cand[mid] <= x) lo_ = mid + 1; else hi_ = mid; }
-    reinterpret_cast<int*>(T + PWL_OFF_GRID)[g] = lo_;
-  }
   // affine map of every piece, PWL_CHUNK pieces per pass:
   //   stage 1, task (p, k): second-layer pre-activation P u + Q on the piece (zeroed if its ReLU is off)
   //   stage 2, task (p, m): theta_m = S u + T
@@ -171,13 +197,66 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
       const double nearest = lo > 0.0 ? lo : (hi < 0.0 ? hi : 0.0);
       const float uref = (float)(nearest < (double)PWL_GMIN ? (double)PWL_GMIN : (nearest > -(double)PWL_GMIN ? -(double)PWL_GMIN : nearest));
       Tt += S * (double)uref;
-      if (m == 0) T[PWL_OFF_REF + p] = uref;
-      if (m < 10) { S *= LOG2E_D; Tt *= LOG2E_D; } else { Tt += sp_offset; }
+      if (m == 0) { T[PWL_OFF_REF + p] = uref; urefs[pl] = (double)uref; }
+      RAW[2 * t] = S;
+      RAW[2 * t + 1] = Tt;
+    }
+    __syncthreads();
+    for (int t = tid; t < np * PWL_P; t += blockDim.x) {
+      const int pl = t >> 4, m = t & 15, p = base + pl;
+      double S = RAW[2 * t], Tt = RAW[2 * t + 1];
+      const double lo = p == 0 ? -INF : cand[p - 1], hi = p < n ? cand[p] : INF;
+      const double uref = urefs[pl];
+      // the part of the piece a sample can reach through an unmarked grid cell
+      const double ulo = fmax(lo, (double)PWL_GMIN - 0.01), uhi = fmin(hi, -(double)PWL_GMIN + 0.01);
+      bool out_of_bounds = false;
+      if (m < 2 * 5) {
+        // shift of the group: its largest logit at the centre of the reachable part of the piece; bounds: the
+        // group maximum at both ends of that part (linear logits: the extremes of the maximum are at the ends
+        // or at the centre, where it is 0 by construction -- the maximum of linear functions is convex)
+        const int r0 = m < 5 ? 0 : 5;
+        const double uc = ulo <= uhi ? 0.5 * (ulo + uhi) : uref;
+        double Mc = -INF, Mlo = -INF, Mhi = -INF;
+        for (int k = r0; k < r0 + 5; ++k) {
+          const double Sk = RAW[2 * (pl * PWL_P + k)], Tk = RAW[2 * (pl * PWL_P + k) + 1];
+          Mc = fmax(Mc, Tk + Sk * (uc - uref));
+          Mlo = fmax(Mlo, Tk + Sk * (ulo - uref));
+          Mhi = fmax(Mhi, Tk + Sk * (uhi - uref));
+        }
+        if (ulo <= uhi)
+          out_of_bounds = fmax(fabs(Mlo - Mc), fabs(Mhi - Mc)) * LOG2E_D > PWL_FAST_LOGIT;
+        S *= LOG2E_D;
+        Tt = (Tt - Mc) * LOG2E_D;
+      } else {
+        Tt += sp_offset;
+        if (ulo <= uhi) {
+          const double a = Tt + S * (ulo - uref), b = Tt + S * (uhi - uref);
+          out_of_bounds = fmin(a, b) < PWL_FAST_SLOPE_LO || fmax(a, b) > PWL_FAST_SLOPE_HI;
+        }
+        S *= LOG2E_D; Tt *= LOG2E_D;
+      }
+      if (out_of_bounds || !(S == S) || !(Tt == Tt)) bad[p] = 1;      // (benign race: everybody writes 1)
       float* row = T + PWL_OFF_PIECE + p * PWL_ROW;
       row[m] = (float)S;
       row[PWL_P + m] = (float)Tt;
     }
     __syncthreads();
+  }
+  // coarse grid: number of breakpoints <= the cell's left edge (a lower bound for the scan).  The edge is
+  // pulled in by 1e-4: pwl_cell() computes the cell in fp32, and u a rounding error below an edge may land
+  // in the cell above it.  Sign bit: the cell touches a piece that needs the general spline evaluation, or is
+  // one of the two outermost cells (which also serve every u outside the grid).
+  for (int g = tid; g < PWL_NG; g += blockDim.x) {
+    const double x = (double)PWL_GMIN + (double)g / (double)PWL_GSCALE - 1e-4;
+    int lo_ = 0, hi_ = g == 0 ? 0 : n;          // cell 0 also serves every u below the grid: scan from piece 0
+    while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (cand[mid] <= x) lo_ = mid + 1; else hi_ = mid; }
+    const double xr = (double)PWL_GMIN + (double)(g + 1) / (double)PWL_GSCALE + 1e-4;
+    int mark = (g == 0 || g == PWL_NG - 1) ? 1 : 0;
+    for (int p = lo_; p <= n && !mark; ++p) {          // pieces lo_ .. the one holding the cell's right edge
+      mark |= bad[p];
+      if (p < n && cand[p] > xr) break;
+    }
+    reinterpret_cast<int*>(T + PWL_OFF_GRID)[g] = lo_ | (mark ? (int)0x80000000 : 0);
   }
 }
 
@@ -221,17 +300,24 @@ __device__ __forceinline__ void pwl_row(const float* tbl, const float* __restric
   }
 }
 
-__device__ __forceinline__ void pwl_eval(const float* tbl, const float* __restrict__ gtbl, float u, float (&th)[PWL_P]) {
-  int p = reinterpret_cast<const int*>(tbl + PWL_OFF_GRID)[pwl_cell(u)];
+// `general`: the sample's grid cell is marked -- the spline must be evaluated the general way (pwl_build_kernel)
+__device__ __forceinline__ void pwl_eval(const float* tbl, const float* __restrict__ gtbl, float u, float (&th)[PWL_P],
+                                         bool& general) {
+  const int g = reinterpret_cast<const int*>(tbl + PWL_OFF_GRID)[pwl_cell(u)];
+  general = g < 0;
+  int p = g & 0x7fffffff;
   const float us = fminf(u, 3.0e38f);            // u = +inf must stop at the +inf padding too
   while (tbl[p] <= us) ++p;                      // bp[>= n] = +inf: terminates
   pwl_row(tbl, gtbl, p, u, th);
 }
 
 // Two samples: both searches advance in ONE loop (half the chain of dependent LDS reads).
-__device__ __forceinline__ void pwl_eval(const float* tbl, const float* __restrict__ gtbl, v2f u, v2f (&th)[PWL_P]) {
+__device__ __forceinline__ void pwl_eval(const float* tbl, const float* __restrict__ gtbl, v2f u, v2f (&th)[PWL_P],
+                                         bool& general) {
   const int* grid = reinterpret_cast<const int*>(tbl + PWL_OFF_GRID);
-  int px = grid[pwl_cell(u.x)], py = grid[pwl_cell(u.y)];
+  const int gx = grid[pwl_cell(u.x)], gy = grid[pwl_cell(u.y)];
+  general = (gx | gy) < 0;
+  int px = gx & 0x7fffffff, py = gy & 0x7fffffff;
   const float ux = fminf(u.x, 3.0e38f), uy = fminf(u.y, 3.0e38f);
   bool more;
   do {

@@ -46,4 +46,4 @@ for l in range(2):
     n = pt.build_table(params[16 + 592 * l: 16 + 592 * (l + 1)].astype(np.float64), float(ts[s]))[0]
     print(f"layer {l} slice {s} c={ts[s]:.3f}: {n.size} breakpoints, range [{n.min() if n.size else 0:.2f}, {n.max() if n.size else 0:.2f}]")
 for i in idx:
-  print(f"sample {i} slice {i // Bs} noise {noise[i]} y64 {y64[i]} err mlp {e0[i]} err tables {e2[i]}")
+  print(f"sample {i} slice {i // Bs} noise {noise[i]} y64 {y64[i]} y_mlp {out[0][i]} y_tables {out[2][i]} err mlp {e0[i]} err tables {e2[i]}")

@@ -246,7 +246,10 @@ def test_config2_piecewise_linear_tables(dev, params_kind):
   # and the tables agree with the MLP kernel far below the oracle tolerance
   eng.set_pwl(0)
   y0, lp0 = eng.sample_logprob(_t(noise, dev), _t(ts, dev))
-  assert (y0 - y).abs().max().item() <= 1e-5 and (lp0 - lp).abs().max().item() <= 1e-5
+  # (an ulp of |log_prob| ~ 200 in the far tail is 1.5e-5: allow 2 ulps on top of the absolute bound)
+  # two fp32 evaluations, each within ~6e-6 of the float64 value (asserted against the oracle above)
+  assert ((y0 - y).abs() - RTOL * y.abs()).max().item() <= 1.5e-5
+  assert ((lp0 - lp).abs() - RTOL * lp.abs()).max().item() <= 1.5e-5
 
 
 @pytest.mark.parametrize("L", [1, 3, 4])
