@@ -64,8 +64,8 @@ enum TabField {
   F_XK,      // x knots [K+1]
   F_YK,      // y knots [K+1]
   F_TAIL,    // d_lo, d_hi, log d_lo, log d_hi, 1/d_lo, 1/d_hi
-  F_XKB,     // -2^60 x x knot j, each stored TWICE ([2 j], [2 j + 1]): a scalar-register pair operand of the
-  F_XKB2,    //   packed clamp-FMA that forms the bin masks of a sample pair (bin_of_scaled); two fields wide
+  F_XKB,     // -2^60 x x knot j, each stored TWICE ([2 j], [2 j + 1]): the ds_read_b64 operand of the packed
+  F_XKB2,    //   clamp-FMA that forms the bin masks of a sample pair (bin_of_pairs); two fields wide
   F_YKB,     // the same for the y knots
   F_YKB2,
   F_COUNT
@@ -289,34 +289,19 @@ template <int K, class R> __device__ __forceinline__ int bin_of(const R* pos, R 
 }
 // Two samples: 0/1 masks [v > knot_j] from ONE packed FMA with the clamp modifier per knot,
 // clamp(v 2^60 - knot_j 2^60) (a single rounding: the sign is that of v - knot_j), summed in fp32 and converted
-// once (v exactly on a knot lands in the lower bin; the spline is continuous there).  11 instructions per pair
-// instead of 26 for per-sample sign-bit arithmetic.
-__device__ __forceinline__ v2f step_fma(v2f v, v2f big, v2f neg_knot_big) {
-  v2f m;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m) : "v"(v), "v"(big), "v"(neg_knot_big));
-  return m;
-}
-template <int K> __device__ __forceinline__ v2i bin_of(const float* pos, v2f v) {
+// once (v exactly on a knot lands in the lower bin; the spline is continuous there).  The prepared table holds
+// -2^60 knot_j twice in a row (F_XKB / F_YKB), so the FMA's third operand is one ds_read_b64 from a uniform
+// address: per knot one LDS read and one VALU instruction (11 VALU per pair in all, against 26 for per-sample
+// sign-bit arithmetic).
+template <int K> __device__ __forceinline__ v2i bin_of_pairs(const float* kb, v2f v) {
   const v2f big = v2f{1.152921504606846976e18f, 1.152921504606846976e18f};       // 2^60
   v2f c = v2f{0.0f, 0.0f};
 #pragma unroll
   for (int j = 1; j < K; ++j) {
-    const float nk = pos[j] * -1.152921504606846976e18f;
-    c += step_fma(v, big, v2f{nk, nk});
-  }
-  return v2i{(int)c.x, (int)c.y};
-}
-// The same with the knots pre-scaled by -2^60 and duplicated in the prepared table (F_XKB / F_YKB), read through
-// the scalar cache: the mask of knot j is ONE instruction, v_pk_fma_f32 v, 2^60, s[pair] clamp.
-template <int K> __device__ __forceinline__ v2i bin_of_scaled(uniform_ptr kb, v2f v) {
-  const v2f big = v2f{1.152921504606846976e18f, 1.152921504606846976e18f};       // 2^60
-  v2f c = v2f{0.0f, 0.0f};
-#pragma unroll
-  for (int j = 1; j < K; ++j) {
-    const v2f nk = v2f{kb[2 * j], kb[2 * j + 1]};
+    const v2f nk = *reinterpret_cast<const v2f*>(kb + 2 * j);
     v2f m;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m) : "v"(v), "v"(big), "s"(nk));
-    c += m;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m) : "v"(v), "v"(big), "v"(nk));
+    c = j == 1 ? m : c + m;
   }
   return v2i{(int)c.x, (int)c.y};
 }
@@ -348,20 +333,13 @@ template <> struct BinRow<v2f> {
   template <int K> __device__ __forceinline__ v2f get(int f) const { return v2f{px[tab_off(f, K)], py[tab_off(f, K)]}; }
 };
 
-// `gprep` (sample pairs only): the prepared table in GLOBAL memory, for the scalar-operand bin masks
 template <int K, bool INV, bool FAST, class T>
 __device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab, T v,
-                                             const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld,
-                                             const float* gprep = nullptr) {
+                                             const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld) {
   typedef typename Lanes<T>::real R;
-  const R* pos = tab + tab_off(INV ? F_YK : F_XK, K);
   typename Lanes<T>::index k;
-  if constexpr (std::is_same<T, v2f>::value) {
-    if (gprep) k = bin_of_scaled<K>(as_uniform(gprep + tab_off(INV ? F_YKB : F_XKB, K)), v);
-    else k = bin_of<K>(pos, v);
-  } else {
-    k = bin_of<K>(pos, v);
-  }
+  if constexpr (std::is_same<T, v2f>::value) k = bin_of_pairs<K>(tab + tab_off(INV ? F_YKB : F_XKB, K), v);
+  else k = bin_of<K>(tab + tab_off(INV ? F_YK : F_XK, K), v);
   const BinRow<T> row(tab, k);
   rqs_bin_eval<INV, FAST, T>(v, row.template get<K>(F_X0), row.template get<K>(F_Y0), row.template get<K>(F_BW),
                              row.template get<K>(F_BH), row.template get<K>(F_IBW),

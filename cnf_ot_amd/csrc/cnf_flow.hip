@@ -549,8 +549,7 @@ template <int K, bool TO_BASE, bool FAST, bool PRECISE = false, bool SHIFT_FREE_
 __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, const float* __restrict__ gtbl,
                                             int L, const SplineConsts& sc, v2f& u0, v2f& u1,
                                             const PreciseConsts* pc = nullptr, const double* e2tab = nullptr,
-                                            const double* tabd = nullptr, BaseAcc<v2f>* bacc = nullptr,
-                                            const float* gprep = nullptr) {
+                                            const double* tabd = nullptr, BaseAcc<v2f>* bacc = nullptr) {
   constexpr bool INV = !TO_BASE;
   static_assert(!PRECISE || TO_BASE, "precise path: data -> base");
   v2f acc = splat<v2f>(0.0f);
@@ -564,7 +563,7 @@ __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, 
       table_spline_precise<K, FAST>(tab, tabd, uf, odd ? lo1 : lo0, sc, of, ld, olo_f);
       if (step == L - 1) bacc->add(of, olo_f);
     } else {
-      table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld, gprep);
+      table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld);
     }
     acc += ld;
     v2f th[PWL_P];
@@ -639,7 +638,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
     if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = (u0 * u0 + u1 * u1) * -0.5f - (float)(2 * HALF_LOG_2PI);
     BaseAcc<v2f> bacc;
     const v2f acc = flow2_tables<K, TO_BASE, FAST, PRECISE, true>(tab, tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, sc,
-                                                            u0, u1, &a.m.scd, e2tab, tabd, &bacc, a.m.prep);
+                                                            u0, u1, &a.m.scd, e2tab, tabd, &bacc);
     if (a.aux) {
       v2f r = acc;
       if constexpr (PRECISE) { if (a.aux_mode == AUX_LOGPROB) r = bacc.log_prob(acc, 2); }

@@ -282,7 +282,7 @@ __device__ __forceinline__ void pwl_row(const float* tbl, const float* __restric
   const float du = u - tbl[PWL_OFF_REF + p];
   if (p < PWL_LROWS) {
     // ONE address per sample; the 8 chunks are immediate offsets of the ds_read_b128s
-    const lds_f4_ptr row = (lds_f4_ptr)(uintptr_t)((uint32_t)(uintptr_t)(tbl + PWL_OFF_PIECE) + (uint32_t)p * (PWL_ROW * 4));
+    const lds_f4_ptr row = (lds_f4_ptr)(uintptr_t)((uint32_t)(uintptr_t)(tbl + PWL_OFF_PIECE) + __umul24((uint32_t)p, PWL_ROW * 4));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f4 s = row[q], t = row[4 + q];
