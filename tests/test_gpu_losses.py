@@ -190,3 +190,40 @@ def test_seeded_terms_equal_tensor_terms(dev):
         assert torch.allclose(a, b, rtol=1e-12, atol=1e-9)
     be.set_samples_per_lane(0)
     be.set_pwl(1)
+
+
+def test_config5_per_gpu_shape_properties(dev):
+  """BASELINE configs[4] at its per-GPU shape: OT obstacle, dim 2, 131 072
+  samples x 32 time-slices (kinetic + obstacle potential on the full slice; the
+  8-GPU config is 2^20 x 32).  Too large for the float64 oracle in seconds, so
+  size-independent properties: finite sums; noise drawn in the kernel == the
+  same stream as a tensor; the table kernels == the MLP kernels (potential to
+  1e-5 relative; the kinetic term is a sum of squared differences amplified by
+  1/dt = 100, two fp32 evaluations of it agree to 5e-5); a 2-way sample
+  sharding of every slice adds up to the whole."""
+  from cnf_ot_amd import applications as app, _capi
+  model, params, _ = _setup(dev)
+  be = model.terms_backend(params)
+  Bs, S = 131072, 32
+  ts = np.linspace(0.0, 1.0, S).astype(np.float32)
+  noise = be.normal(42, Bs)
+  res = {}
+  for pwl in (0, 2):
+    be.set_pwl(pwl)
+    for name, spec in (("kinetic", app._spec(_capi.TERM_KINETIC, dt=0.01)),
+                       ("obstacle", app._spec(_capi.TERM_POTENTIAL, subtype=_capi.POTENTIALS["obstacle"]))):
+      a = be.loss_terms(spec, noise, ts, Bs, True)
+      assert be.last_path() == ("loss_tables" if pwl else "loss_mlp")
+      b = be.loss_terms_seeded(spec, 42, ts, Bs, first_sample=0, slice_stride=0)
+      assert torch.isfinite(a).all() and (a >= 0).all()
+      assert torch.allclose(a, b, rtol=1e-12, atol=1e-9), (name, pwl)
+      h = Bs // 2        # two ranks' blocks of every slice (distributed.shard_range)
+      parts = be.loss_terms(spec, noise[:h].contiguous(), ts, h, True) + \
+        be.loss_terms(spec, noise[h:].contiguous(), ts, h, True)
+      assert torch.allclose(parts, a, rtol=1e-9), (name, pwl)
+      res[(name, pwl)] = a
+  for name in ("kinetic", "obstacle"):
+    rel = ((res[(name, 0)] - res[(name, 2)]).abs() / res[(name, 0)].abs().clamp_min(1e-30)).max().item()
+    print(f"\n[cfg5 {name}] tables vs mlp: max relative difference over {S} slices {rel:.2e}")
+    assert rel <= (5e-5 if name == "kinetic" else 1e-5)
+  be.set_pwl(1)
