@@ -29,6 +29,10 @@ from . import _capi
 from .distributed import Shard, all_reduce_sums, current_shard, shard_range
 from .flows import seed_to_u64
 
+# Cholesky factor L (lower: A = L L^T, applied as z @ L like oracle/losses.py) of the Gaussian source's covariance A = [[5, 1], [1, .5]]
+# (applications.py:28-32), computed once: torch.linalg.cholesky of a 2 x 2 CPU tensor costs ~20 ms PER CALL on a
+# 256-thread host (LAPACK thread start-up) -- it was 35 of the 41 ms of config 5's value_and_grad.
+GAUSSIAN_SOURCE_CHOL = np.linalg.cholesky(np.array([[5.0, 1.0], [1.0, 0.5]])).astype(np.float32)
 MIXTURE_R = 5.0
 # applications.py:34-67: centres of the 8-mode mixture source
 MIXTURE_CENTERS = MIXTURE_R * np.array(
@@ -104,7 +108,7 @@ def _source_samples(ctx, z, start, count, n_global, source):
   if source == "gaussian":     # applications.py:28-32 (commented Gaussian source; BASELINE configs)
     if z.shape[1] != 2:
       raise ValueError("the Gaussian source N(-3, A) is 2-D (applications.py:28-32)")
-    chol = torch.linalg.cholesky(torch.tensor([[5.0, 1.0], [1.0, 0.5]], dtype=torch.float64)).to(z.dtype).to(z.device)
+    chol = torch.from_numpy(GAUSSIAN_SOURCE_CHOL).to(z.device)      # lower factor, applied as z @ L like the round-1 code
     return z @ chol - 3.0
   raise ValueError(f"unknown source {source!r}")
 

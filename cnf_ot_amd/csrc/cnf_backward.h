@@ -319,6 +319,247 @@ __device__ __forceinline__ WgradPre wgrad_prefetch(const float* __restrict__ gw,
 }
 
 // ---------------------------------------------------------------------------
+// The backward pass's conditioner work on the matrix cores (hidden 16, P = 16, one sample per lane).  A lone or
+// second wave per SIMD -- all the backward kernels' LDS working set allows -- issues one VALU instruction per ~8
+// cycles, and the 544-FMA conditioner recompute plus the two 256-FMA data-backprop products are most of a
+// backward pass; as 16x16x4 fp32 MFMAs they are 64 instructions.  Everything stays in the MFMA operand layout of
+// conditioner_mfma (lane (g, s), register r: unit 4g + r of sample 16q + s of group q) from the recompute through
+// the ReLU masks to the weight-gradient staging; only theta (out), theta_bar (in) and the first-layer adjoint
+// cross to / from the lane-per-sample layout, by the same 4x4 permlane transpose.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void to_mfma_layout(const float (&v)[16], float (&m)[4][4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x0 = v[r], x1 = v[4 + r], x2 = v[8 + r], x3 = v[12 + r];
+    transpose4(x0, x1, x2, x3);
+    m[0][r] = x0; m[1][r] = x1; m[2][r] = x2; m[3][r] = x3;
+  }
+}
+__device__ __forceinline__ void from_mfma_layout(const float (&m)[4][4], float (&v)[16]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x0 = m[0][r], x1 = m[1][r], x2 = m[2][r], x3 = m[3][r];
+    transpose4(x0, x1, x2, x3);
+    v[r] = x0; v[4 + r] = x1; v[8 + r] = x2; v[12 + r] = x3;
+  }
+}
+
+// MFMA-layout values -> a staging region ([unit][sample], row stride STG): unit 4g + t of sample 16q + i
+__device__ __forceinline__ void stage_m(float* region, const float (&m)[4][4]) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) region[(4 * g + t) * STG + 16 * q + i] = m[q][t];
+  }
+}
+// bit 4q + t: m[q][t] > 0 (the ReLU mask of a hidden layer, 16 bits instead of 16 registers)
+__device__ __forceinline__ uint32_t mask_m(const float (&m)[4][4]) {
+  uint32_t bits = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bits |= (m[q][t] > 0.0f ? 1u : 0u) << (4 * q + t);
+  }
+  return bits;
+}
+
+constexpr int STAGE_FLOATS = 3 * 16 * STG;       // per wave: [h1 operand, kept][a operand][b operand]
+
+// conditioner forward (M = 2) on MFMA for the backward pass: theta in lane layout, the second hidden layer's
+// activations in MFMA layout, the first one's STAGED in the wave's h1 region (it is only needed again as a
+// weight-gradient operand) with its ReLU mask as 16 bits; `wq` as in conditioner_mfma
+__device__ __forceinline__ void conditioner_mfma_keep(const f4* __restrict__ wq, int d, float c, const float* col,
+                                                      int first_idx, int idx_step, int stride, float* stage,
+                                                      uint32_t& mask1, float (&h2m)[4][4], float (&th)[16]) {
+  const int lane = threadIdx.x & 63, s15 = lane & 15;
+  float h1m[4][4];
+  {
+    const f4 w0c = wq[lane];
+    const f4 b0 = wq[(1 + d) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float cq = lane_fetch(4 * (16 * q + s15), c);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h1m[q][t] = fmaf(w0c[t], cq, b0[t]);
+    }
+  }
+  for (int row = 0; row < d; ++row) {
+    const float v = col[(first_idx + row * idx_step) * stride];
+    const f4 w = wq[(1 + row) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float vq = lane_fetch(4 * (16 * q + s15), v);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h1m[q][t] = fmaf(w[t], vq, h1m[q][t]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h1m[q][t] = fmaxf(h1m[q][t], 0.0f);
+  }
+  mask1 = mask_m(h1m);
+  __builtin_amdgcn_wave_barrier();
+  stage_m(stage, h1m);
+  __builtin_amdgcn_wave_barrier();
+  const f4* p = wq + (2 + d) * 64;
+  f4 acc[4];
+  {
+    const f4 A = p[lane], bias = p[64 + lane];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = bias;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t], h1m[q][t], acc[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h2m[q][t] = fmaxf(acc[q][t], 0.0f);
+    }
+  }
+  {
+    const f4 A = p[128 + lane], bias = p[192 + lane];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = bias;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t], h2m[q][t], acc[q], 0, 0, 0);
+    }
+  }
+  float thm[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) thm[q][r] = acc[q][r];
+  }
+  from_mfma_layout(thm, th);
+}
+
+// dW += a b^T over the wave's 64 samples from STAGED operands ([unit][sample] regions)
+__device__ __forceinline__ void wgrad_staged(const float* sa, const float* sb, float* __restrict__ dW,
+                                             float* __restrict__ db, WgradAcc pre) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+  f4 av[4], bv[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    av[n] = *reinterpret_cast<const f4*>(sa + i * STG + 16 * g + 4 * n);
+    bv[n] = *reinterpret_cast<const f4*>(sb + i * STG + 16 * g + 4 * n);
+  }
+  f4 acc = pre.acc;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[n][e], bv[n][e], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dW[(4 * g + r) * 16 + i] = acc[r];
+  if (db) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) sum += (bv[n][0] + bv[n][1]) + (bv[n][2] + bv[n][3]);
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (g == 0) db[i] = pre.bias + sum;
+  }
+}
+
+// Conditioner backward with the two data-backprop products on MFMA.  `wflat`: this conditioner's weights in the
+// flat layout (global memory): the A operand of out_i = sum_j W[i][j] in_j is W[i][4g .. 4g+3], one 16-byte load.
+// `stage`: [h1 region (filled by conditioner_mfma_keep)][a][b].
+template <bool WGRAD = true>
+__device__ __forceinline__ void conditioner_bwd_mfma(const float* __restrict__ wflat, uniform_ptr w, int d, float c,
+                                                     const float* col, int first_idx, int idx_step, int stride,
+                                                     uint32_t mask1, const float (&h2m)[4][4],
+                                                     const float (&tb)[16], float* adj_col, float* __restrict__ gw,
+                                                     float* stage, const WgradPre& pre) {
+  w = launder(w);
+  const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+  const int o_b0 = (1 + d) * 16, o_w1 = o_b0 + 16, o_b1 = o_w1 + 256, o_wo = o_b1 + 16, o_bo = o_wo + 256;
+  float* s1 = stage;
+  float* sa = stage + 16 * STG;
+  float* sb = stage + 32 * STG;
+  const uint32_t mask2 = mask_m(h2m);
+  float tbm[4][4];
+  to_mfma_layout(tb, tbm);
+  if constexpr (WGRAD) {
+    __builtin_amdgcn_wave_barrier();
+    stage_m(sa, h2m);
+    stage_m(sb, tbm);
+    __builtin_amdgcn_wave_barrier();
+    wgrad_staged(sa, sb, gw + o_wo, gw + o_bo, pre.o);
+  }
+  float g2m[4][4];
+  {
+    const f4 Ao = *reinterpret_cast<const f4*>(wflat + o_wo + i * 16 + 4 * g);
+    f4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ao[t], tbm[q][t], acc[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g2m[q][r] = (mask2 >> (4 * q + r)) & 1u ? acc[q][r] : 0.0f;
+    }
+  }
+  if constexpr (WGRAD) {
+    __builtin_amdgcn_wave_barrier();
+    stage_m(sb, g2m);
+    __builtin_amdgcn_wave_barrier();
+    wgrad_staged(s1, sb, gw + o_w1, gw + o_b1, pre.h);
+  }
+  float g1[16];
+  {
+    const f4 A1 = *reinterpret_cast<const f4*>(wflat + o_w1 + i * 16 + 4 * g);
+    f4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[t], g2m[q][t], acc[q], 0, 0, 0);
+    }
+    float g1m[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g1m[q][r] = (mask1 >> (4 * q + r)) & 1u ? acc[q][r] : 0.0f;
+    }
+    from_mfma_layout(g1m, g1);
+  }
+  // first layer: inputs [c, v_0..v_{d-1}, 1] (the constant row yields the bias gradient), lane layout
+  if constexpr (WGRAD) {
+    float in[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) in[r] = 0.0f;
+    in[0] = c;
+    for (int q = 0; q < d && q < 14; ++q) {
+      const float v = col[(first_idx + q * idx_step) * stride];
+#pragma unroll
+      for (int r = 1; r < 15; ++r) in[r] = (r == q + 1) ? v : in[r];
+    }
+#pragma unroll
+    for (int r = 1; r < 16; ++r) in[r] = (r == d + 1) ? 1.0f : in[r];
+    wgrad_mfma(sa, in, g1, gw, d + 2, nullptr, pre.f);
+  }
+  for (int q = 0; q < d; ++q) {          // adjoints of the conditioning inputs
+    float wr[16];
+    load_row<16>(w + (1 + q) * 16, wr);
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc = fmaf(wr[j], g1[j], acc);
+    adj_col[(first_idx + q * idx_step) * stride] += acc;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Conditioner backward (M = 2).  theta_bar -> weight gradients (into the
 // wave's slab `gw`, laid out like the flat parameters of this conditioner) and
 // adjoints of the d conditioning inputs (accumulated into adj_col).

@@ -26,6 +26,24 @@ constexpr int GP = 3 * GK + 1;     // 16 spline parameters
 // MFMA staging per wave, and at 1 wave per SIMD a wave issues at half rate with every latency exposed).
 #define GTS ((int)blockDim.x)
 constexpr int GTS_MAX = TILE;
+// experiment switches (scripts/exp_backward.sh; never set by the product build):
+//   CNF_BWD_VALU  the conditioner of the backward kernels on the vector ALU (the round-1 form)
+//   CNF_BWD_OCC1  let the backward kernels use up to 512 registers (one wave per SIMD)
+#ifdef CNF_BWD_VALU
+constexpr bool BWD_MFMA = false;
+#else
+constexpr bool BWD_MFMA = true;
+#endif
+#ifdef CNF_FWD_VALU
+constexpr bool FWD_MFMA = false;
+#else
+constexpr bool FWD_MFMA = true;
+#endif
+#ifdef CNF_BWD_OCC1
+#define CNF_BWD_MIN_BLOCKS 1
+#else
+#define CNF_BWD_MIN_BLOCKS 2
+#endif
 
 struct GradArgs {
   ModelArgs m;
@@ -83,10 +101,16 @@ __device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, const float*
     co[first_idx * GTS] = o;
     acc += ld;
     uniform_ptr w = weights + l * a.per_layer;
+    [[maybe_unused]] const float* wq = a.wq + l * a.per_layer_q;
     for (int d = 1; d < D; ++d) {
       const int i = first_idx + d * idx_step;
       float th[GP];
-      conditioner<16, GP, float>(w, d, 2, c, to_base ? co : cu, first_idx, idx_step, GTS, th);
+      if constexpr (FAST && BWD_MFMA && FWD_MFMA) {        // matrix cores (see cnf_backward.h); `wq` walks the MFMA-layout weights
+        conditioner_mfma<float>(reinterpret_cast<const f4*>(wq), d, 2, c, to_base ? co : cu, first_idx, idx_step, GTS, th);
+        wq += cond_floats_mfma(d, 2);
+      } else {
+        conditioner<16, GP, float>(w, d, 2, c, to_base ? co : cu, first_idx, idx_step, GTS, th);
+      }
       if (to_base) cond_spline<GK, false, FAST, float>(th, cu[i * GTS], a.sc, o, ld);
       else cond_spline<GK, true, FAST, float>(th, cu[i * GTS], a.sc, o, ld);
       co[i * GTS] = o;
@@ -118,21 +142,41 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab,
     float* au = Au + threadIdx.x;
     for (int d = 0; d < D; ++d) au[d * GTS] = 0.0f;
     int64_t off = cond_prefix(D);                     // end of this layer's conditioners
+    [[maybe_unused]] int64_t offq = 0;                 // the same in the MFMA-layout weights
+    if constexpr (FAST && BWD_MFMA) { for (int dd = 1; dd < D; ++dd) offq += cond_floats_mfma(dd, 2); }
     for (int d = D - 1; d >= 1; --d) {
       off -= cond_floats(d, 16, 2, GP);
       const int i = first_idx + d * idx_step;
       uniform_ptr w = weights + l * a.per_layer + off;
       float* gw = WGRAD ? gslab + GP + l * a.per_layer + off : nullptr;
       WgradPre pre;
-      if constexpr (WGRAD) pre = wgrad_prefetch(gw, d);
-      float h1[16], h2[16], th[GP], tb[GP];
-      conditioner_keep(w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, h1, h2, th);
-      float vb;
-      if (to_base) vb = cond_spline_bwd<GK, false, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
-      else vb = cond_spline_bwd<GK, true, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
-      au[i * GTS] += vb;
-      conditioner_bwd<WGRAD>(w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, h1, h2, tb, to_base ? ao : au,
-                             gw, stage, pre);
+      float th[GP], tb[GP];
+      if constexpr (FAST && BWD_MFMA) {      // recompute and data backprop on the matrix cores (cnf_backward.h)
+        offq -= cond_floats_mfma(d, 2);
+        uint32_t mask1;
+        float h2m[4][4];
+        conditioner_mfma_keep(reinterpret_cast<const f4*>(a.wq + l * a.per_layer_q + offq), d, c, to_base ? co : cu,
+                              first_idx, idx_step, GTS, stage, mask1, h2m, th);
+        // the accumulator tiles: fetched here, ~300 instructions (the spline backward) ahead of their first use;
+        // any earlier and the 15 registers they occupy push the kernel past 256 (2 waves per SIMD)
+        if constexpr (WGRAD) pre = wgrad_prefetch(gw, d);
+        float vb;
+        if (to_base) vb = cond_spline_bwd<GK, false, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
+        else vb = cond_spline_bwd<GK, true, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
+        au[i * GTS] += vb;
+        conditioner_bwd_mfma<WGRAD>(a.prep + hdr_floats(GK) + l * a.per_layer + off, w, d, c, to_base ? co : cu,
+                                    first_idx, idx_step, GTS, mask1, h2m, tb, to_base ? ao : au, gw, stage, pre);
+      } else {
+        if constexpr (WGRAD) pre = wgrad_prefetch(gw, d);
+        float h1[16], h2[16];
+        conditioner_keep(w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, h1, h2, th);
+        float vb;
+        if (to_base) vb = cond_spline_bwd<GK, false, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
+        else vb = cond_spline_bwd<GK, true, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
+        au[i * GTS] += vb;
+        conditioner_bwd<WGRAD>(w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, h1, h2, tb, to_base ? ao : au,
+                               gw, stage ? stage + 16 * STG : nullptr, pre);
+      }
     }
     float vb0;
     if (to_base) vb0 = table_spline_bwd<GK, false>(tab, cu[first_idx * GTS], co[first_idx * GTS], ao[first_idx * GTS],
@@ -192,7 +236,7 @@ enum Role {
 };
 
 template <bool FAST>
-__global__ __launch_bounds__(GTS_MAX, 1) void grad_kernel(const GradArgs a) {
+__global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void grad_kernel(const GradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HDR = hdr_floats(GK);
   const int D = a.m.D, L = a.m.L;
@@ -206,7 +250,7 @@ __global__ __launch_bounds__(GTS_MAX, 1) void grad_kernel(const GradArgs a) {
   float* R3 = V + DT;
   float* R3b = R3 + DT;
   float* Ub = R3b + DT;
-  float* stage = Ub + DT + (threadIdx.x >> 6) * (2 * 16 * STG);
+  float* stage = Ub + DT + (threadIdx.x >> 6) * STAGE_FLOATS;
   for (int i = threadIdx.x; i < HDR; i += GTS) tab[i] = a.m.prep[i];
   const int tid = threadIdx.x;
   const int kind = a.spec.kind;
@@ -425,7 +469,7 @@ struct VjpArgs {
 // WGRAD=true additionally accumulates the parameter gradient of the pass (the
 // backward of a differentiable flow op: cnf_pass_vjp).
 template <bool FAST, bool WGRAD>
-__global__ __launch_bounds__(GTS_MAX, WGRAD ? 1 : 2) void vjp_kernel(const VjpArgs a) {
+__global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void vjp_kernel(const VjpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HDR = hdr_floats(GK);
   const int D = a.m.D, L = a.m.L, DT = D * GTS;
@@ -433,7 +477,7 @@ __global__ __launch_bounds__(GTS_MAX, WGRAD ? 1 : 2) void vjp_kernel(const VjpAr
   float* St = lds + HDR;
   float* Aa = St + (L + 1) * DT;
   float* Ab = Aa + DT;
-  float* stage = WGRAD ? Ab + DT + (threadIdx.x >> 6) * (2 * 16 * STG) : nullptr;
+  float* stage = Ab + DT + (threadIdx.x >> 6) * STAGE_FLOATS;       // (WGRAD = false: only the h1 region is touched)
   float* gslab = WGRAD ? a.slabs + ((int64_t)blockIdx.x * (GTS >> 6) + (threadIdx.x >> 6)) * a.n_params : nullptr;
   for (int i = threadIdx.x; i < HDR; i += GTS) tab[i] = a.m.prep[i];
   const int tid = threadIdx.x;
@@ -706,10 +750,11 @@ using namespace cnf;
 #undef GTS
 static size_t grad_lds_bytes(int D, int L, int ts = GTS_MAX) {
   // tab + noise + (L+1) stashes + 2 adjoint buffers + velocity, r3, r3_bar, u_bar + one MFMA staging area per wave
-  return (size_t)(hdr_floats(GK) + D * ts * (1 + (L + 1) + 6) + (ts / 64) * 2 * 16 * STG) * sizeof(float);
+  return (size_t)(hdr_floats(GK) + D * ts * (1 + (L + 1) + 6) + (ts / 64) * STAGE_FLOATS) * sizeof(float);
 }
 static size_t vjp_lds_bytes(int D, int L, int ts, bool wgrad) {
-  return (size_t)(hdr_floats(GK) + D * ts * ((L + 1) + 2) + (wgrad ? (ts / 64) * 2 * 16 * STG : 0)) * sizeof(float);
+  (void)wgrad;       // the MFMA recompute stages h1 even without weight gradients
+  return (size_t)(hdr_floats(GK) + D * ts * ((L + 1) + 2) + (ts / 64) * STAGE_FLOATS) * sizeof(float);
 }
 // The tile size (threads per workgroup) that puts the most waves on a CU: LDS allows 160 KB / lds(ts) workgroups
 // of ts / 64 waves; the backward kernels' ~230 VGPRs allow 8 waves (2 per SIMD).  Ties go to the larger tile.

@@ -3,7 +3,7 @@
   python scripts/kernel_resources.py cnf_ot_amd/csrc/cnf_flow.hip [--full]"""
 import os, re, subprocess, sys, tempfile
 src = sys.argv[1]
-flags = [] if "--full" in sys.argv else ["-DCNF_MINIMAL_CONFIGS"]
+flags = ([] if "--full" in sys.argv else ["-DCNF_MINIMAL_CONFIGS"]) + os.environ.get("CNF_EXTRA_FLAGS", "").split()
 out = os.path.join(tempfile.gettempdir(), os.path.basename(src) + ".s")
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", *flags, "-S", "--cuda-device-only",
                 src, "-o", out], check=True, capture_output=True)

@@ -61,7 +61,10 @@ def _run(dev, D, kind_spec, B, n_slices, shared, scale_params, seed, rtol, name)
   grad = torch.zeros(cfg.param_count(), device=dev)
   sums = eng.loss_terms_grad(kind_spec, pts, t, B, shared, 1.0, grad)
   sums_fwd = eng.loss_terms(kind_spec, pts, t, B, shared)
-  assert torch.allclose(sums, sums_fwd, rtol=1e-6, atol=1e-6), (sums, sums_fwd)
+  # the gradient kernel evaluates the conditioner on the matrix cores, the loss kernel on the vector ALU: two fp32
+  # evaluation orders.  The finite-difference terms amplify the difference by 1/dt and 1/dx = 100.
+  fd_term = kind_spec.kind <= 2
+  assert torch.allclose(sums, sums_fwd, rtol=5e-5 if fd_term else 2e-6, atol=1e-6), (sums, sums_fwd)
   # a second call accumulates and is deterministic
   grad2 = torch.zeros_like(grad)
   eng.loss_terms_grad(kind_spec, pts, t, B, shared, 1.0, grad2)
