@@ -65,6 +65,7 @@ SYMBOLS = {
   "cnf_log_prob_f64": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _P]),
   "cnf_sample_logprob_f64": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
   "cnf_fill_normal": (ctypes.c_int, [_U64, _U64, _I64, _P, _P]),
+  "cnf_fill_normal_threefry": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint32, _U64, _U64, _I64, _P, _P, _P]),
   "cnf_loss_terms": (ctypes.c_int, [_P, ctypes.POINTER(CnfLossSpec), _P, ctypes.c_int, _P, _I64, _I64, _P, _P]),
   "cnf_loss_terms_seeded": (ctypes.c_int, [_P, ctypes.POINTER(CnfLossSpec), _U64, _I64, _I64, _P, _I64, _I64, _P, _P]),
   "cnf_grad_supported": (ctypes.c_int, [_CFG]),

@@ -1005,6 +1005,47 @@ __global__ void fill_normal_kernel(uint64_t seed, uint64_t first_element, int64_
   }
 }
 
+// ---------------------------------------------------------------------------
+// JAX-compatible base draw: jax.random.normal(key, (n, D), float64) as the reference makes it
+// (conditional.py:378,399 -> distrax Normal -> jax.random.normal; float64 because solvers.py:23 enables x64), for the
+// classic (non-"partitionable") threefry bit generation: element j of the flattened [size] draw takes the 64 bits
+// (o0 << 32) | o1 of the Threefry-2x32-20 block with counter (j, size + j) and key (k0, k1)
+// [threefry_2x32 splits the iota of 2 size counters in halves; the 64-bit combine takes the halves of the output],
+// maps them to a uniform in [nextafter(-1, 0), 1) through the mantissa of a double in [1, 2), and returns
+// sqrt(2) erfinv(u).  The Threefry function is pinned by the Random123 known-answer vectors (tests); the bit ->
+// normal mapping restates jax._src.random (un-pinned JAX version, not installable here: cannot be compared with
+// JAX itself -- "parity unpinned" for this entry point).
+// ---------------------------------------------------------------------------
+__host__ __device__ inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__host__ __device__ inline void threefry2x32_20(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t& o0,
+                                                uint32_t& o1) {
+  const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  const int rot[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+  uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+  for (int g = 0; g < 5; ++g) {
+    for (int r = 0; r < 4; ++r) { x0 += x1; x1 = rotl32(x1, rot[g & 1][r]); x1 ^= x0; }
+    x0 += ks[(g + 1) % 3];
+    x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+  o0 = x0; o1 = x1;
+}
+
+__global__ void fill_normal_threefry_kernel(uint32_t k0, uint32_t k1, uint64_t size, uint64_t first, int64_t n,
+                                            float* __restrict__ out32, double* __restrict__ out64) {
+  const double lo = -0.99999999999999988897769753748;        // nextafter(-1, 0)
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t j = first + (uint64_t)i;
+    uint32_t o0, o1;
+    threefry2x32_20(k0, k1, (uint32_t)j, (uint32_t)(size + j), o0, o1);
+    const uint64_t bits = ((uint64_t)o0 << 32) | (uint64_t)o1;
+    const double f = __longlong_as_double((long long)((bits >> 12) | 0x3FF0000000000000ull)) - 1.0;
+    const double u = fmax(lo, f * (1.0 - lo) + lo);
+    const double z = 1.41421356237309504880 * erfinv(u);
+    if (out64) out64[i] = z;
+    if (out32) out32[i] = (float)z;
+  }
+}
+
 }  // namespace cnf
 
 // ===========================================================================
@@ -1575,6 +1616,18 @@ extern "C" int cnf_sample_logprob(CnfModel* m, const float* noise, const float* 
                                   float* y, float* logp, int64_t B, void* stream) {
   if (!y) return CNF_ERR_INVALID;
   return run_flow(m, false, noise, c, c_block, y, logp, AUX_LOGPROB, B, stream);
+}
+
+extern "C" int cnf_fill_normal_threefry(uint32_t key0, uint32_t key1, uint64_t size, uint64_t first_element, int64_t n,
+                                        float* out_f32, double* out_f64, void* stream) {
+  if (n < 0 || (n > 0 && !out_f32 && !out_f64) || first_element + (uint64_t)n > size || size > 0x7fffffffull)
+    return CNF_ERR_INVALID;        // (2 size 32-bit counters: jax's single-block case)
+  if (n == 0) return CNF_OK;
+  int64_t grid = (n + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(fill_normal_threefry_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, key0, key1,
+                     size, first_element, n, out_f32, out_f64);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 
 extern "C" int cnf_logprob_fd(CnfModel* m, const float* pts, const float* c, int64_t c_block, float dx,

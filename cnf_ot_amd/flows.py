@@ -461,6 +461,24 @@ class FlowEngine:
       J[:, i, :] = self.input_vjp(pts, cond, ybar=e, to_base=to_base)
     return J
 
+  def normal_threefry(self, key, n_samples: int, first_sample: int = 0, total_samples: int = None,
+                      dtype=torch.float32) -> torch.Tensor:
+    """cnf_fill_normal_threefry: rows [first_sample, first_sample + n_samples) of
+    jax.random.normal(key, (total_samples, D), float64) (classic threefry path), as `dtype`."""
+    k0, k1 = jax_key_words(key)
+    D = self.cfg.dim
+    total = n_samples + first_sample if total_samples is None else total_samples
+    out = torch.empty(n_samples, D, dtype=dtype, device=self.device)
+    if n_samples > 0:
+      f32 = out.data_ptr() if dtype == torch.float32 else None
+      f64 = out.data_ptr() if dtype == torch.float64 else None
+      if f32 is None and f64 is None:
+        raise ValueError("dtype must be float32 or float64")
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_fill_normal_threefry(k0, k1, total * D, first_sample * D, n_samples * D, f32, f64,
+                                                      _stream_ptr(self.device)), "cnf_fill_normal_threefry")
+    return out
+
   def normal(self, seed, n_samples: int, first_sample: int = 0) -> torch.Tensor:
     """Base noise [n_samples, D]: Philox stream element (first_sample+i)*D+d."""
     seed, off = seed_to_u64(seed)
@@ -476,6 +494,20 @@ class FlowEngine:
 def _sets_of(spec) -> int:
   """table sets per slice of a fused loss term: conditions t -+ dt/2 (and t)."""
   return 2 if spec.kind == _capi.TERM_KINETIC else (3 if spec.kind <= _capi.TERM_FLOW_MATCHING else 1)
+
+
+def jax_key_words(seed) -> Tuple[int, int]:
+  """The two uint32 words of a JAX PRNG key: a 2-word array is taken as is; an int like jax.random.PRNGKey(int)
+  ((seed >> 32) & 0xffffffff, seed & 0xffffffff)."""
+  if torch.is_tensor(seed) or isinstance(seed, np.ndarray):
+    words = [int(v) for v in np.asarray(seed.cpu() if torch.is_tensor(seed) else seed).reshape(-1)]
+    if len(words) == 2:
+      return words[0] & 0xFFFFFFFF, words[1] & 0xFFFFFFFF
+    if len(words) != 1:
+      raise ValueError("a JAX key has two uint32 words")
+    seed = words[0]
+  seed = int(seed)
+  return (seed >> 32) & 0xFFFFFFFF, seed & 0xFFFFFFFF
 
 
 def _num_samples(sample_shape) -> Tuple[int, Tuple[int, ...]]:
@@ -512,7 +544,8 @@ class _Apply:
     if noise is None:
       if seed is None:
         raise ValueError("sample needs `seed` (or explicit base `noise`)")
-      noise = eng.normal(seed, n)
+      # rng = "threefry": `seed` is a JAX key and the draw is jax.random.normal's (conditional.py:378,399)
+      noise = eng.normal_threefry(seed, n) if self._m.rng == "threefry" else eng.normal(seed, n)
     elif tuple(noise.shape) != (n, eng.cfg.dim):
       raise ValueError(f"noise must have shape {(n, eng.cfg.dim)}, got {tuple(noise.shape)}")
     return noise, shape
@@ -561,8 +594,11 @@ class FlowModel:
   """What the reference's driver holds after
   ``hk.without_apply_rng(hk.multi_transform(RQSFlow(...)))`` (solvers.py:41-48)."""
 
-  def __init__(self, cfg: FlowConfig):
+  def __init__(self, cfg: FlowConfig, rng: str = "philox"):
+    if rng not in ("philox", "threefry"):
+      raise ValueError("rng must be 'philox' (the build's own stream) or 'threefry' (jax.random.normal's)")
     self.cfg = cfg
+    self.rng = rng
     self._engines = {}
     a = _Apply(self)
     self.apply = Flow(a.log_prob, a.sample, a.sample_and_log_prob, a.forward, a.inverse,
@@ -605,8 +641,11 @@ def RQSFlow(
   periodized: bool = False,
   cond_shape=(1,),
   base_range=(0, 2 * math.pi),
+  rng: str = "philox",
 ) -> FlowModel:
-  """Same signature as cnf_ot/models/flows.py:178-186."""
+  """Same signature as cnf_ot/models/flows.py:178-186 (+ `rng`: "philox" = the
+  build's own counter-based stream, "threefry" = `seed` is a JAX key and the
+  base draw of sample / sample_and_log_prob is jax.random.normal's)."""
   if periodized:
     raise NotImplementedError(
       "periodized=True (circular boundary slopes on [0, 2pi]) is not on the mfc hot "
@@ -621,4 +660,4 @@ def RQSFlow(
   cfg = FlowConfig(dim=int(event_shape[0]), num_layers=int(num_layers),
                    hidden_size=int(hidden_sizes[0]), mlp_num_layers=len(hidden_sizes),
                    num_bins=int(num_bins))
-  return FlowModel(cfg)
+  return FlowModel(cfg, rng=rng)

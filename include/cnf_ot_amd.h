@@ -184,6 +184,19 @@ int cnf_sample_logprob_f64(CnfModel *m, const double *noise, const double *c,
 int cnf_fill_normal(uint64_t seed, uint64_t first_element, int64_t n,
                     float *out, void *stream);
 
+/* The same draw as JAX makes it: jax.random.normal(key, shape, float64) with
+ * prod(shape) = `size`, key data (key0, key1) (jax.random.PRNGKey(seed) is
+ * (seed >> 32, seed & 0xffffffff)), classic (non-partitionable) threefry bit
+ * generation; elements [first_element, first_element + n) of the flattened
+ * draw, as float32 and / or float64 (either pointer may be NULL).  Threefry-2x32
+ * is pinned by the Random123 known answers; the bits -> normal mapping restates
+ * jax._src.random and could not be compared with JAX itself (not installable
+ * where this was built): use it to reproduce a reference run's base noise, and
+ * verify on a JAX box before relying on bit-level agreement. */
+int cnf_fill_normal_threefry(uint32_t key0, uint32_t key1, uint64_t size,
+                             uint64_t first_element, int64_t n, float *out_f32,
+                             double *out_f64, void *stream);
+
 /* ---- fused Monte-Carlo loss terms (cnf_ot/mfc/applications.py) ------------
  * One launch evaluates one term over n_slices time-slices x B samples and
  * returns, per slice, the SUM over that slice's samples (double, device); the

@@ -7,6 +7,7 @@ Parity status: **parity unpinned** in absolute value against distrax (the
 reference's spline arithmetic lives in the absent third-party package distrax,
 and the reference holds no golden vectors); see ``cnf_oracle_impl.h``.
 """
+from .capi import threefry2x32, normal_threefry  # noqa: F401
 from .capi import (  # noqa: F401
   OracleConfig,
   build_library,

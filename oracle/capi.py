@@ -190,3 +190,25 @@ def normal(seed: int, first_element: int, n: int) -> np.ndarray:
   if rc != 0:
     raise RuntimeError("cnf_oracle_normal_f64 failed")
   return out
+
+
+def threefry2x32(key, ctr):
+  """One Threefry-2x32-20 block: (key0, key1), (ctr0, ctr1) -> (out0, out1)."""
+  k = (ctypes.c_uint32 * 2)(*[int(v) & 0xFFFFFFFF for v in key])
+  c = (ctypes.c_uint32 * 2)(*[int(v) & 0xFFFFFFFF for v in ctr])
+  o = (ctypes.c_uint32 * 2)()
+  load_library().cnf_oracle_threefry2x32(k, c, o)
+  return int(o[0]), int(o[1])
+
+
+def normal_threefry(key, size: int, first_element: int = 0, n: int = None) -> np.ndarray:
+  """jax.random.normal(key, shape with prod = size, float64), classic threefry path: elements
+  [first_element, first_element + n) of the flattened draw."""
+  n = size - first_element if n is None else n
+  out = np.empty(n, dtype=np.float64)
+  rc = load_library().cnf_oracle_normal_threefry_f64(
+    ctypes.c_uint32(int(key[0]) & 0xFFFFFFFF), ctypes.c_uint32(int(key[1]) & 0xFFFFFFFF), ctypes.c_uint64(size),
+    ctypes.c_uint64(first_element), ctypes.c_int64(n), _ptr(out))
+  if rc != 0:
+    raise RuntimeError("cnf_oracle_normal_threefry_f64 failed")
+  return out

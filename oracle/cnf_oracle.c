@@ -6,6 +6,7 @@
 #include "cnf_oracle.h"
 
 #include <math.h>
+#include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -115,6 +116,69 @@ int cnf_oracle_normal_f64(uint64_t seed, uint64_t first_element, int64_t n,
     double u2 = (double)(u[2 * p + 1] >> 8) * (1.0 / 16777216.0);
     double rad = sqrt(-2.0 * log(u1)), ang = two_pi * u2;
     out[i] = (r & 1) ? rad * sin(ang) : rad * cos(ang);
+  }
+  return 0;
+}
+
+/* ---- Threefry-2x32-20 (Salmon et al. 2011, Random123) and the JAX-style normal draw --------------------------
+ * Restates jax._src.prng.threefry_2x32 / threefry_random_bits (classic, non-partitionable path) and
+ * jax._src.random._uniform / _normal_real for float64: see cnf_ot_amd/csrc/cnf_flow.hip fill_normal_threefry_kernel.
+ * The block function is pinned by the Random123 known-answer vectors (tests/test_oracle_flow.py). */
+static uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+void cnf_oracle_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]) {
+  const uint32_t ks[3] = {key[0], key[1], key[0] ^ key[1] ^ 0x1BD11BDAu};
+  static const int rot[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+  uint32_t x0 = ctr[0] + ks[0], x1 = ctr[1] + ks[1];
+  for (int g = 0; g < 5; ++g) {
+    for (int r = 0; r < 4; ++r) { x0 += x1; x1 = rotl32(x1, rot[g & 1][r]); x1 ^= x0; }
+    x0 += ks[(g + 1) % 3];
+    x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+  out[0] = x0; out[1] = x1;
+}
+
+/* erfinv by Newton-Halley on libm's erf from a rational start (glibc has no erfinv) */
+static double erfinv_newton(double y) {
+  if (y <= -1.0) return -INFINITY;
+  if (y >= 1.0) return INFINITY;
+  double w = -log((1.0 - y) * (1.0 + y)), x;
+  if (w < 5.0) {
+    w -= 2.5;
+    x = 2.81022636e-08; x = 3.43273939e-07 + x * w; x = -3.5233877e-06 + x * w; x = -4.39150654e-06 + x * w;
+    x = 0.00021858087 + x * w; x = -0.00125372503 + x * w; x = -0.00417768164 + x * w; x = 0.246640727 + x * w;
+    x = 1.50140941 + x * w;
+  } else {
+    w = sqrt(w) - 3.0;
+    x = -0.000200214257; x = 0.000100950558 + x * w; x = 0.00134934322 + x * w; x = -0.00367342844 + x * w;
+    x = 0.00573950773 + x * w; x = -0.0076224613 + x * w; x = 0.00943887047 + x * w; x = 1.00167406 + x * w;
+    x = 2.83297682 + x * w;
+  }
+  x *= y;
+  for (int it = 0; it < 3; ++it) {
+    const double e = erf(x) - y, d = 1.1283791670955126 * exp(-x * x);      /* 2/sqrt(pi) exp(-x^2) */
+    x -= e / (d + x * e);                                                    /* Halley: f'' / f' = -2x */
+  }
+  return x;
+}
+
+int cnf_oracle_normal_threefry_f64(uint32_t key0, uint32_t key1, uint64_t size, uint64_t first_element, int64_t n,
+                                   double *out) {
+  const double lo = nextafter(-1.0, 0.0);
+  const uint32_t key[2] = {key0, key1};
+  if (first_element + (uint64_t)n > size || size > 0x7fffffffull) return -1;
+  for (int64_t i = 0; i < n; ++i) {
+    const uint64_t j = first_element + (uint64_t)i;
+    const uint32_t ctr[2] = {(uint32_t)j, (uint32_t)(size + j)};
+    uint32_t o[2];
+    cnf_oracle_threefry2x32(key, ctr, o);
+    const uint64_t bits = (((uint64_t)o[0] << 32) | (uint64_t)o[1]) >> 12 | 0x3FF0000000000000ull;
+    double f;
+    memcpy(&f, &bits, sizeof f);
+    f -= 1.0;
+    double u = f * (1.0 - lo) + lo;
+    if (u < lo) u = lo;
+    out[i] = 1.41421356237309504880 * erfinv_newton(u);
   }
   return 0;
 }

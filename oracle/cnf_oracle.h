@@ -70,4 +70,9 @@ void cnf_oracle_set_num_threads(int n);
 #ifdef __cplusplus
 }
 #endif
+/* Threefry-2x32-20 and the JAX-style float64 normal draw built on it (see cnf_oracle.c) */
+void cnf_oracle_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]);
+int cnf_oracle_normal_threefry_f64(uint32_t key0, uint32_t key1, uint64_t size, uint64_t first_element, int64_t n,
+                                   double *out);
+
 #endif

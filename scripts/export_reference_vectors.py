@@ -18,6 +18,8 @@ for D in (2, 10):
   c = jnp.asarray([0.37])
   y = model.apply.forward(params, x, c)                     # base -> data
   out = {f"{m}/{n}": np.asarray(a) for m, d in params.items() for n, a in d.items()}
+  key = jax.random.PRNGKey(7)          # the base draw of conditional.py:378,399, to pin cnf_fill_normal_threefry
+  out.update(key_words=np.asarray(jax.random.key_data(key)), noise=np.asarray(jax.random.normal(key, (1000, D))))
   out.update(x=np.asarray(x), c=np.asarray(c), y=np.asarray(y),
              log_prob_y=np.asarray(model.apply.log_prob(params, y, c)),
              x_back=np.asarray(model.apply.inverse(params, y, c)))

@@ -731,3 +731,24 @@ def test_float64_kernels_match_oracle_to_1e12(golden_dir, dev, name):
       worst = max(worst, e.max())
   print(f"\n[f64 {name}] worst relative-or-absolute error {worst:.2e}")
   assert worst <= tol
+
+
+def test_threefry_normals_match_oracle(dev):
+  """cnf_fill_normal_threefry (the JAX-style draw) == the C restatement, as float64 bit for bit up to erfinv's last
+  bits and as float32; sharded calls reproduce the whole draw; model.apply.sample(rng="threefry") uses it."""
+  import oracle
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params, RQSFlow
+  cfg = FlowConfig(dim=2)
+  eng = FlowEngine(cfg, dev).load(Params.zeros(cfg, dev))
+  n = 50001
+  want = oracle.normal_threefry((7, 42), n * 2).reshape(n, 2)
+  got64 = eng.normal_threefry(np.array([7, 42], dtype=np.uint32), n, dtype=torch.float64)
+  assert np.abs(got64.cpu().numpy() - want).max() <= 1e-13
+  got32 = eng.normal_threefry(np.array([7, 42], dtype=np.uint32), n)
+  assert np.abs(got32.cpu().numpy().astype(np.float64) - want).max() <= 5e-7
+  a = eng.normal_threefry((7 << 32) | 42, 1000, first_sample=123, total_samples=n, dtype=torch.float64)
+  assert torch.equal(a, got64[123:1123])
+  model = RQSFlow(event_shape=(2,), num_layers=2, hidden_sizes=[16, 16], num_bins=5, rng="threefry")
+  y = model.apply.sample(Params.zeros(cfg, dev), cond=torch.tensor([0.5], device=dev),
+                         seed=np.array([7, 42], dtype=np.uint32), sample_shape=(n,))
+  assert (y - got32).abs().max().item() <= 1e-6      # identity flow: the samples are the base draw

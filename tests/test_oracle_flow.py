@@ -194,3 +194,29 @@ def test_reference_vectors_if_present(oracle_lib, golden_dir):
     assert np.abs(oracle.log_prob(cfg, params, g["y"], g["c"]) - g["log_prob_y"]).max() <= 1e-9
     xb, _ = oracle.inverse_logdet(cfg, params, g["y"], g["c"])
     assert np.abs(xb - g["x_back"]).max() <= 1e-9
+    if "noise" in g.files:         # the JAX-style base draw (classic threefry path; newer JAX may default to another)
+      z = oracle.normal_threefry(tuple(int(v) for v in g["key_words"]), g["noise"].size).reshape(g["noise"].shape)
+      assert np.abs(z - g["noise"]).max() <= 1e-12
+
+
+def test_threefry_known_answers_and_jax_style_normals(oracle_lib):
+  """the JAX-compatible base draw.  Threefry-2x32-20 against the Random123 known-answer vectors
+  (the ones JAX's own test suite uses); the float64 normal built on it is standard normal, offset-consistent, and
+  its erfinv agrees with scipy's.  (The bits -> normal mapping restates jax._src.random and cannot be compared with
+  JAX here: parity unpinned for the sampler as a whole.)"""
+  from scipy import special, stats
+  kat = [((0, 0), (0, 0), (0x6b200159, 0x99ba4efe)),
+         ((0xffffffff, 0xffffffff), (0xffffffff, 0xffffffff), (0x1cb996fc, 0xbb002be7)),
+         ((0x243f6a88, 0x85a308d3), (0x13198a2e, 0x03707344), (0xc4923a9c, 0x483df7a0))]
+  for ctr, key, want in kat:
+    assert oracle.threefry2x32(key, ctr) == want
+  size = 100000
+  z = oracle.normal_threefry((0, 42), size)
+  assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01 and stats.kstest(z, "norm").pvalue > 1e-3
+  part = oracle.normal_threefry((0, 42), size, first_element=777, n=1000)      # a shard of the same draw
+  assert np.array_equal(part, z[777:1777])
+  assert not np.array_equal(oracle.normal_threefry((0, 43), size)[:100], z[:100])
+  # the draw depends on the total size (the second counter word is size + j), like jax's
+  assert not np.array_equal(oracle.normal_threefry((0, 42), size + 2)[:100], z[:100])
+  # erfinv: z / sqrt(2) inverts erf
+  assert np.abs(special.erf(z / np.sqrt(2)) - special.erf(special.erfinv(special.erf(z / np.sqrt(2))))).max() < 1e-15
