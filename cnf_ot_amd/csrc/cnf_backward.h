@@ -327,23 +327,6 @@ __device__ __forceinline__ WgradPre wgrad_prefetch(const float* __restrict__ gw,
 // the ReLU masks to the weight-gradient staging; only theta (out), theta_bar (in) and the first-layer adjoint
 // cross to / from the lane-per-sample layout, by the same 4x4 permlane transpose.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void to_mfma_layout(const float (&v)[16], float (&m)[4][4]) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float x0 = v[r], x1 = v[4 + r], x2 = v[8 + r], x3 = v[12 + r];
-    transpose4(x0, x1, x2, x3);
-    m[0][r] = x0; m[1][r] = x1; m[2][r] = x2; m[3][r] = x3;
-  }
-}
-__device__ __forceinline__ void from_mfma_layout(const float (&m)[4][4], float (&v)[16]) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float x0 = m[0][r], x1 = m[1][r], x2 = m[2][r], x3 = m[3][r];
-    transpose4(x0, x1, x2, x3);
-    v[r] = x0; v[4 + r] = x1; v[8 + r] = x2; v[12 + r] = x3;
-  }
-}
-
 // MFMA-layout values -> a staging region ([unit][sample], row stride STG): unit 4g + t of sample 16q + i
 __device__ __forceinline__ void stage_m(float* region, const float (&m)[4][4]) {
   const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
@@ -369,35 +352,55 @@ constexpr int STAGE_FLOATS = 3 * 16 * STG;       // per wave: [h1 operand, kept]
 // conditioner forward (M = 2) on MFMA for the backward pass: theta in lane layout, the second hidden layer's
 // activations in MFMA layout, the first one's STAGED in the wave's h1 region (it is only needed again as a
 // weight-gradient operand) with its ReLU mask as 16 bits; `wq` as in conditioner_mfma
-__device__ __forceinline__ void conditioner_mfma_keep(const f4* __restrict__ wq, int d, float c, const float* col,
-                                                      int first_idx, int idx_step, int stride, float* stage,
-                                                      uint32_t& mask1, float (&h2m)[4][4], float (&th)[16]) {
-  const int lane = threadIdx.x & 63, s15 = lane & 15;
-  float h1m[4][4];
-  {
-    const f4 w0c = wq[lane];
-    const f4 b0 = wq[(1 + d) * 64 + lane];
+// theta only (the forward-with-stash pass of the backward kernels): first layer as above, the two 16 x 16 layers on
+// the matrix cores
+__device__ __forceinline__ void conditioner_mfma_lane1(const f4* __restrict__ wq, uniform_ptr w, int d, float c,
+                                                       const float* col, int first_idx, int idx_step, int stride,
+                                                       float (&th)[16]) {
+  const int lane = threadIdx.x & 63;
+  const f4* p = wq + (2 + d) * 64;
+  const f4 A1 = p[lane], bias1 = p[64 + lane], A2 = p[128 + lane], bias2 = p[192 + lane];
+  float h1[16], hm[4][4];
+  first_layer_lane<float>(w, d, c, col, first_idx, idx_step, stride, h1);
+  to_mfma_layout(h1, hm);
+  f4 acc[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float cq = lane_fetch(4 * (16 * q + s15), c);
+  for (int q = 0; q < 4; ++q) acc[q] = bias1;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) h1m[q][t] = fmaf(w0c[t], cq, b0[t]);
-    }
-  }
-  for (int row = 0; row < d; ++row) {
-    const float v = col[(first_idx + row * idx_step) * stride];
-    const f4 w = wq[(1 + row) * 64 + lane];
+  for (int t = 0; t < 4; ++t) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float vq = lane_fetch(4 * (16 * q + s15), v);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) h1m[q][t] = fmaf(w[t], vq, h1m[q][t]);
-    }
+    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[t], hm[q][t], acc[q], 0, 0, 0);
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) h1m[q][t] = fmaxf(h1m[q][t], 0.0f);
+    for (int t = 0; t < 4; ++t) hm[q][t] = fmaxf(acc[q][t], 0.0f);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = bias2;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[t], hm[q][t], acc[q], 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hm[q][r] = acc[q][r];
+  }
+  from_mfma_layout(hm, th);
+}
+
+__device__ __forceinline__ void conditioner_mfma_keep(const f4* __restrict__ wq, uniform_ptr w, int d, float c,
+                                                      const float* col,
+                                                      int first_idx, int idx_step, int stride, float* stage,
+                                                      uint32_t& mask1, float (&h2m)[4][4], float (&th)[16]) {
+  const int lane = threadIdx.x & 63;
+  float h1m[4][4];
+  {
+    float h1[16];
+    first_layer_lane<float>(w, d, c, col, first_idx, idx_step, stride, h1);
+    to_mfma_layout(h1, h1m);
   }
   mask1 = mask_m(h1m);
   __builtin_amdgcn_wave_barrier();

@@ -885,16 +885,80 @@ __device__ __forceinline__ void transpose4(float& x0, float& x1, float& x2, floa
 __device__ __forceinline__ void set_comp(float& dst, int, float v) { dst = v; }
 __device__ __forceinline__ void set_comp(v2f& dst, int i, float v) { if (i == 0) dst.x = v; else dst.y = v; }
 
+// lane-per-sample layout (16 values per lane) <-> MFMA operand layout (lane (g, s), register r: unit 4g + r of
+// sample 16q + s of group q): the same 4x4 permlane transpose both ways
+__device__ __forceinline__ void to_mfma_layout(const float (&v)[16], float (&m)[4][4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x0 = v[r], x1 = v[4 + r], x2 = v[8 + r], x3 = v[12 + r];
+    transpose4(x0, x1, x2, x3);
+    m[0][r] = x0; m[1][r] = x1; m[2][r] = x2; m[3][r] = x3;
+  }
+}
+__device__ __forceinline__ void from_mfma_layout(const float (&m)[4][4], float (&v)[16]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x0 = m[0][r], x1 = m[1][r], x2 = m[2][r], x3 = m[3][r];
+    transpose4(x0, x1, x2, x3);
+    v[r] = x0; v[4 + r] = x1; v[8 + r] = x2; v[12 + r] = x3;
+  }
+}
+
+// First hidden layer in the lane-per-sample layout with SCALAR weights (the 16 (1 + d) FMAs are the same count in
+// either layout, but the MFMA-layout form reads one weight vector per input row from global memory inside a
+// runtime loop: d + 2 dependent ~1 us round trips per conditioner at dim 10, against scalar-cache loads the
+// scheduler issues ahead), then one 4x4 permlane transpose into the MFMA operand layout.
+template <class T>
+__device__ __forceinline__ void first_layer_lane(uniform_ptr w, int d, T c, const float* col, int first_idx,
+                                                 int idx_step, int stride, T (&h1)[16]) {
+  w = launder(w);
+  uniform_ptr b0 = w + (1 + d) * 16;
+  {
+    float wc[16], bb[16];
+    load_row<16>(w, wc); load_row<16>(b0, bb);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h1[j] = vfma(wc[j], c, splat<T>(bb[j]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int q = 0; q < d; ++q) {
+    const T v = lds_get<T>(col, first_idx + q * idx_step, stride);
+    float wr[16];
+    load_row<16>(w + (1 + q) * 16, wr);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h1[j] = vfma(wr[j], v, h1[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) h1[j] = vrelu(h1[j]);
+}
+
+// `wflat` (optional): the conditioner's weights in the flat layout; with it the first hidden layer is evaluated in
+// the lane layout with scalar weights and transposed (first_layer_lane above) -- no dependent vector loads per
+// input row.
 template <class T>
 __device__ __forceinline__ void conditioner_mfma(const f4* __restrict__ wq, int d, int M, T c,
                                                  const float* col, int first_idx, int idx_step,
-                                                 int stride, T (&th)[16]) {
+                                                 int stride, T (&th)[16], uniform_ptr wflat = nullptr) {
   constexpr int N = Lanes<T>::N;
   constexpr int Q = 4 * N;
   const int lane = threadIdx.x & 63;
   const int s15 = lane & 15;
   float h[Q][4];
-  {
+  if (wflat) {
+    T h1[16];
+    first_layer_lane<T>(wflat, d, c, col, first_idx, idx_step, stride, h1);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      float hv[16], m[4][4];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) hv[j] = comp_of(h1[j], n);
+      to_mfma_layout(hv, m);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[qq * N + n][r] = m[qq][r];
+      }
+    }
+  } else {
     const f4 w0c = wq[lane];
     const f4 b0 = wq[(1 + d) * 64 + lane];
 #pragma unroll
@@ -904,7 +968,7 @@ __device__ __forceinline__ void conditioner_mfma(const f4* __restrict__ wq, int 
       for (int t = 0; t < 4; ++t) h[q][t] = fmaf(w0c[t], cq, b0[t]);
     }
   }
-  for (int row = 0; row < d; ++row) {          // runtime loop over the d conditioning inputs
+  for (int row = 0; row < d && !wflat; ++row) {          // runtime loop over the d conditioning inputs
     const T v = lds_get<T>(col, first_idx + row * idx_step, stride);
     const f4 w = wq[(1 + row) * 64 + lane];
 #pragma unroll
@@ -921,10 +985,11 @@ __device__ __forceinline__ void conditioner_mfma(const f4* __restrict__ wq, int 
   }
   const f4* p = wq + (2 + d) * 64;
   f4 acc[Q];
+  f4 A_next = p[lane], bias_next = p[64 + lane];      // the next layer's operands are fetched one layer ahead:
   for (int m = 1; m <= M; ++m) {               // M-1 hidden 16x16 layers + the 16x16 output layer
-    const f4 A = p[lane];
-    const f4 bias = p[64 + lane];
+    const f4 A = A_next, bias = bias_next;     // a ~1 us round trip otherwise waited for at every layer
     p += 128;
+    if (m < M) { A_next = p[lane]; bias_next = p[64 + lane]; }
 #pragma unroll
     for (int q = 0; q < Q; ++q) acc[q] = bias;
 #pragma unroll

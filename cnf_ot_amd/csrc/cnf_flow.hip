@@ -302,8 +302,9 @@ __device__ __forceinline__ T flow_pass(const ModelArgs& a, const typename Lanes<
       const int i = first_idx + d * idx_step;
       T th[P];
       if constexpr (MFMA && !std::is_same<T, double>::value) {
-        conditioner_mfma<T>(reinterpret_cast<const f4*>(wq), d, a.M, c, TO_BASE ? co : cu, first_idx, idx_step, TS, th);
+        conditioner_mfma<T>(reinterpret_cast<const f4*>(wq), d, a.M, c, TO_BASE ? co : cu, first_idx, idx_step, TS, th, w);
         wq += cond_floats_mfma(d, a.M);
+        w += cond_floats(d, H, a.M, P);
       } else {
         conditioner<H, P, T>(w, d, a.M, c, TO_BASE ? co : cu, first_idx, idx_step, TS, th);
         w += cond_floats(d, H, a.M, P);

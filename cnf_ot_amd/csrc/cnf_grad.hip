@@ -106,7 +106,7 @@ __device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, const float*
       const int i = first_idx + d * idx_step;
       float th[GP];
       if constexpr (FAST && BWD_MFMA && FWD_MFMA) {        // matrix cores (see cnf_backward.h); `wq` walks the MFMA-layout weights
-        conditioner_mfma<float>(reinterpret_cast<const f4*>(wq), d, 2, c, to_base ? co : cu, first_idx, idx_step, GTS, th);
+        conditioner_mfma_lane1(reinterpret_cast<const f4*>(wq), w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, th);
         wq += cond_floats_mfma(d, 2);
       } else {
         conditioner<16, GP, float>(w, d, 2, c, to_base ? co : cu, first_idx, idx_step, GTS, th);
@@ -155,7 +155,7 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab,
         offq -= cond_floats_mfma(d, 2);
         uint32_t mask1;
         float h2m[4][4];
-        conditioner_mfma_keep(reinterpret_cast<const f4*>(a.wq + l * a.per_layer_q + offq), d, c, to_base ? co : cu,
+        conditioner_mfma_keep(reinterpret_cast<const f4*>(a.wq + l * a.per_layer_q + offq), w, d, c, to_base ? co : cu,
                               first_idx, idx_step, GTS, stage, mask1, h2m, th);
         // the accumulator tiles: fetched here, ~300 instructions (the spline backward) ahead of their first use;
         // any earlier and the 15 registers they occupy push the kernel past 256 (2 waves per SIMD)
