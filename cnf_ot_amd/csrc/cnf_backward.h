@@ -485,6 +485,13 @@ __device__ __forceinline__ void conditioner_bwd_mfma(const float* __restrict__ w
   float* s1 = stage;
   float* sa = stage + 16 * STG;
   float* sb = stage + 32 * STG;
+  // both A operands now: two independent L2 round trips that would otherwise be waited for one after the other,
+  // right in front of their MFMAs
+  const f4 Ao = *reinterpret_cast<const f4*>(wflat + o_wo + i * 16 + 4 * g);
+  const f4 A1 = *reinterpret_cast<const f4*>(wflat + o_w1 + i * 16 + 4 * g);
+#ifdef CNF_BWD_HOIST_A
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   const uint32_t mask2 = mask_m(h2m);
   float tbm[4][4];
   to_mfma_layout(tb, tbm);
@@ -497,7 +504,6 @@ __device__ __forceinline__ void conditioner_bwd_mfma(const float* __restrict__ w
   }
   float g2m[4][4];
   {
-    const f4 Ao = *reinterpret_cast<const f4*>(wflat + o_wo + i * 16 + 4 * g);
     f4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
@@ -520,7 +526,6 @@ __device__ __forceinline__ void conditioner_bwd_mfma(const float* __restrict__ w
   }
   float g1[16];
   {
-    const f4 A1 = *reinterpret_cast<const f4*>(wflat + o_w1 + i * 16 + 4 * g);
     f4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
