@@ -2,6 +2,7 @@
 // (cnf_flow.hip: forward kernels + C ABI; cnf_grad.hip: backward + Adam).
 #pragma once
 #include <mutex>
+#include <map>
 #include <unordered_map>
 #include <vector>
 
@@ -127,14 +128,16 @@ static inline bool ensure_lds(K kernel, size_t bytes) {
   if (bytes > 160 * 1024) return false;
   if (bytes <= 64 * 1024) return true;
   static std::mutex mu;
-  static std::unordered_map<int, bool> done;       // one map per kernel instantiation, keyed by device
+  // keyed by (kernel, device): kernels of one signature share this instantiation
+  static std::map<std::pair<const void*, int>, bool> done;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   std::lock_guard<std::mutex> lock(mu);
-  auto it = done.find(dev);
+  const auto key = std::make_pair((const void*)kernel, dev);
+  auto it = done.find(key);
   if (it != done.end()) return it->second;
   const bool ok = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-  done[dev] = ok;
+  done[key] = ok;
   return ok;
 }
 

@@ -85,6 +85,17 @@ template <class R> struct SplineConstsT {
 };
 typedef SplineConstsT<float> SplineConsts;
 
+// The constants of a kernel argument as individually pinned scalars.  Read through a reference into the (4-byte
+// aligned) argument struct, the vectoriser pairs lo / hi / span_eff into <2 x float> loads and routes them through
+// a 16-byte scratch copy that every tile then re-loads with vector-memory latency (seen in flow_pwl_kernel).
+__device__ __forceinline__ SplineConsts sc_scalars(const SplineConsts& s) {
+  float lo = s.lo, hi = s.hi, span = s.span_eff, mb = s.min_bin, ms = s.min_slope, so = s.sp_offset;
+  asm volatile("" : "+s"(lo), "+s"(hi), "+s"(span), "+s"(mb), "+s"(ms), "+s"(so));
+  SplineConsts r;
+  r.lo = lo; r.hi = hi; r.span_eff = span; r.min_bin = mb; r.min_slope = ms; r.sp_offset = so;
+  return r;
+}
+
 // ---------------------------------------------------------------------------
 // Elementwise helpers over T in {float, v2f}
 // ---------------------------------------------------------------------------
@@ -218,7 +229,7 @@ template <> struct Math<true> {
 
 // softplus(t + offset) + m  (distrax _normalize_knot_slopes)
 template <bool FAST, class T, bool OFFSET_ADDED = false>
-__device__ __forceinline__ T knot_slope(T t, const SplineConstsT<typename Lanes<T>::real>& sc) {
+__device__ __forceinline__ T knot_slope(T t, const SplineConstsT<typename Lanes<T>::real> sc) {
   const T v = OFFSET_ADDED ? t : t + sc.sp_offset;
   const T av = vabs(v);
   const T e = Math<FAST>::exp(-av);
@@ -335,7 +346,7 @@ template <> struct BinRow<v2f> {
 
 template <int K, bool INV, bool FAST, class T>
 __device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab, T v,
-                                             const SplineConstsT<typename Lanes<T>::real>& sc, T& out, T& ld) {
+                                             const SplineConstsT<typename Lanes<T>::real> sc, T& out, T& ld) {
   typedef typename Lanes<T>::real R;
   typename Lanes<T>::index k;
   if constexpr (std::is_same<T, v2f>::value) k = bin_of_pairs<K>(tab + tab_off(INV ? F_YKB : F_XKB, K), v);
@@ -385,7 +396,7 @@ __device__ __forceinline__ v2f step_mask(v2f d, v2f big) {
 // Otherwise the general form: running maximum, the log1p series for slope arguments near zero.
 template <int K, bool INV, bool FAST, bool SHIFT_FREE>
 __device__ __forceinline__ void cond_spline_masked(const v2f (&th)[3 * K + 1], v2f v,
-                                                   const SplineConsts& sc, v2f& out, v2f& ld) {
+                                                   const SplineConsts sc, v2f& out, v2f& ld) {
   using M = Math<FAST>;
   typedef v2f T;
   T ew[K], eh[K];
@@ -445,6 +456,105 @@ __device__ __forceinline__ void cond_spline_masked(const v2f (&th)[3 * K + 1], v
     // t LN2 + |round(t LN2)| is the product's rounding error instead of 0, and a slope at its floor of 1e-4 is
     // then off by up to ulp(|t|) -- found by the soak (scripts/soak_pwl.py), tails with |u| >> 16.
     T n0 = t0 * LN2, n1 = t1 * LN2;
+    asm volatile("" : "+v"(n0), "+v"(n1));
+    d0 = knot_slope<FAST, T, true>(n0, sc);
+    d1 = knot_slope<FAST, T, true>(n1, sc);
+  }
+  const T ibw = M::rcp(bw);
+  const T s = bh * ibw;
+  const T st = d1 + d0 - s * 2.0f;
+  rqs_bin_eval<INV, FAST, T, false>(v, x0, y0, bw, bh, ibw, s, st, d0, d1, s, out, ld);
+  if (maybe_outside(v, sc.lo, sc.hi)) {
+    const auto below = vle(v, sc.lo);          // bin 0 was selected: d0 = slope[0]
+    const auto above = vge(v, sc.hi);          // bin K-1 was selected: d1 = slope[K]
+    const T lo_out = INV ? M::div(v - sc.lo, d0) + sc.lo : vfma(v - sc.lo, d0, splat<T>(sc.lo));
+    const T hi_out = INV ? M::div(v - sc.hi, d1) + sc.hi : vfma(v - sc.hi, d1, splat<T>(sc.hi));
+    const T ld0 = M::log(d0), ld1 = M::log(d1);
+    out = vsel(below, lo_out, out);
+    ld = vsel(below, INV ? -ld0 : ld0, ld);
+    out = vsel(above, hi_out, out);
+    ld = vsel(above, INV ? -ld1 : ld1, ld);
+  }
+}
+
+// cond_spline_masked with the table rows evaluated where they are cheapest (round 2).  The two samples of a lane sit
+// in unrelated rows, so a row's 16 FMAs cannot be packed ACROSS the samples -- but neighbouring parameters of ONE
+// sample are neighbours in its row: qa / qb hold the 2K softmax logits of sample a / b as K pairs
+// (logit 2j, logit 2j+1), one v_pk_fma_f32 per pair (K per sample instead of 2K v_fma_f32), and the exponentials
+// -- scalar instructions anyway -- write their results into the sample-pair layout the rest of the spline uses.
+// The slope logits are not evaluated for all K + 1 knots and then selected with masks: the bin index (the sum of
+// the 0/1 masks) addresses the row a second time and `slopes(ka, kb, ta, tb)` returns (t_k, t_k+1) of each sample
+// from one packed FMA.  Same values bit for bit as cond_spline_masked on the same rows.
+template <int K, bool INV, bool FAST, bool SHIFT_FREE, class SlopeFetch>
+__device__ __forceinline__ void cond_spline_rows(const v2f (&qa)[K], const v2f (&qb)[K], SlopeFetch&& slopes, v2f v,
+                                                 const SplineConsts sc, v2f& out, v2f& ld) {
+  using M = Math<FAST>;
+  typedef v2f T;
+  auto la = [&](int j) { return qa[j >> 1][j & 1]; };
+  auto lb = [&](int j) { return qb[j >> 1][j & 1]; };
+  T ew[K], eh[K];
+  T aw, ah;
+  if constexpr (SHIFT_FREE) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      ew[k] = v2f{__builtin_amdgcn_exp2f(la(k)), __builtin_amdgcn_exp2f(lb(k))};
+      eh[k] = v2f{__builtin_amdgcn_exp2f(la(K + k)), __builtin_amdgcn_exp2f(lb(K + k))};
+    }
+    T sw = ew[0] + ew[1], sh = eh[0] + eh[1];
+#pragma unroll
+    for (int k = 2; k < K; ++k) { sw += ew[k]; sh += eh[k]; }
+    const T r = M::rcp(sw * sh) * sc.span_eff;
+    aw = r * sh; ah = r * sw;
+  } else {
+    float mwa = la(0), mwb = lb(0), mha = la(K), mhb = lb(K);
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+      mwa = fmaxf(mwa, la(k)); mwb = fmaxf(mwb, lb(k));
+      mha = fmaxf(mha, la(K + k)); mhb = fmaxf(mhb, lb(K + k));
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      ew[k] = v2f{__builtin_amdgcn_exp2f(la(k) - mwa), __builtin_amdgcn_exp2f(lb(k) - mwb)};
+      eh[k] = v2f{__builtin_amdgcn_exp2f(la(K + k) - mha), __builtin_amdgcn_exp2f(lb(K + k) - mhb)};
+    }
+    T sw = ew[0], sh = eh[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) { sw += ew[k]; sh += eh[k]; }
+    aw = M::rcp(sw) * sc.span_eff; ah = M::rcp(sh) * sc.span_eff;
+  }
+  const T big = splat<T>(1.152921504606846976e18f);       // 2^60
+  T px = splat<T>(sc.lo), py = splat<T>(sc.lo);            // running knot k
+  T wp = vfma(ew[0], aw, splat<T>(sc.min_bin)), hp = vfma(eh[0], ah, splat<T>(sc.min_bin));   // bin k-1
+  T x0 = px, y0 = py;
+  T mprev = splat<T>(1.0f), bw = splat<T>(0.0f), bh = splat<T>(0.0f), kf = splat<T>(0.0f);
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    px += wp;
+    py += hp;
+    const T m = step_mask(v - (INV ? py : px), big);
+    const T o = mprev - m;                                  // one-hot of bin k-1
+    bw = k == 1 ? o * wp : vfma(o, wp, bw);
+    bh = k == 1 ? o * hp : vfma(o, hp, bh);
+    kf = k == 1 ? m : kf + m;                               // masks are monotone: their sum is the bin index
+    x0 = vfma(m, wp, x0);
+    y0 = vfma(m, hp, y0);
+    if (k == K - 1) { wp = sc.hi - px; hp = sc.hi - py; }   // last knot is exactly hi
+    else { wp = vfma(ew[k], aw, splat<T>(sc.min_bin)); hp = vfma(eh[k], ah, splat<T>(sc.min_bin)); }
+    mprev = m;
+  }
+  bw = vfma(mprev, wp, bw);
+  bh = vfma(mprev, hp, bh);
+  v2f ta, tb;                                               // (t_k, t_k+1) of sample a, of sample b
+  slopes((int)kf.x, (int)kf.y, ta, tb);
+  T d0, d1;
+  if constexpr (SHIFT_FREE) {      // softplus(t) + m = ln2 log2(1 + 2^(t log2 e)) + m, t in [-3, 40]
+    const T l0 = v2f{__builtin_amdgcn_logf(__builtin_amdgcn_exp2f(ta.x) + 1.0f), __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(tb.x) + 1.0f)};
+    const T l1 = v2f{__builtin_amdgcn_logf(__builtin_amdgcn_exp2f(ta.y) + 1.0f), __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(tb.y) + 1.0f)};
+    d0 = vfma(l0, splat<T>(LN2), splat<T>(sc.min_slope));
+    d1 = vfma(l1, splat<T>(LN2), splat<T>(sc.min_slope));
+  } else {
+    // natural units; the product is ROUNDED before knot_slope forms v + |v| (see cond_spline_masked)
+    T n0 = v2f{ta.x, tb.x} * LN2, n1 = v2f{ta.y, tb.y} * LN2;
     asm volatile("" : "+v"(n0), "+v"(n1));
     d0 = knot_slope<FAST, T, true>(n0, sc);
     d1 = knot_slope<FAST, T, true>(n1, sc);

@@ -15,6 +15,7 @@
 //    set) into a 12-float-per-bin table that is staged in LDS and gathered by
 //    per-lane bin index.
 #include "cnf_common.h"
+#include <cstdlib>
 #include "cnf_pwl.h"
 
 #include <math.h>
@@ -533,13 +534,14 @@ __global__ void cond_uniform_kernel(const float* __restrict__ c, int64_t B, uint
 }
 
 // Stage the L tables of (set, slice) into LDS: header arrays + the rows in use, at most PWL_LROWS.
+template <int LROWS = PWL_LROWS>
 __device__ __forceinline__ void pwl_stage(float* tbl, const float* __restrict__ g0, int L, int tid, int nthreads) {
   for (int l = 0; l < L; ++l) {
     const float* g = g0 + (int64_t)l * PWL_TBL;
     const int n = __float_as_int(g[PWL_N_SLOT]);                       // pieces 0 .. n
-    const int rows = n + 1 < PWL_LROWS ? n + 1 : PWL_LROWS;
+    const int rows = n + 1 < LROWS ? n + 1 : LROWS;
     const f4* src = reinterpret_cast<const f4*>(g);
-    f4* dst = reinterpret_cast<f4*>(tbl + l * PWL_LTBL);
+    f4* dst = reinterpret_cast<f4*>(tbl + l * pwl_ltbl(LROWS));
     for (int i = tid; i < (PWL_OFF_PIECE + rows * PWL_ROW) / 4; i += nthreads) dst[i] = src[i];
   }
 }
@@ -549,9 +551,9 @@ __device__ __forceinline__ void pwl_stage(float* tbl, const float* __restrict__ 
 // returns the accumulated log|det J| of the direction.
 // SHIFT_FREE_OK: use the shift-free spline evaluation where the sample's grid cell allows it (the flow kernels;
 // the loss kernel, at its register limit with three table sets, always evaluates the general form).
-template <int K, bool TO_BASE, bool FAST, bool PRECISE = false, bool SHIFT_FREE_OK = false>
+template <int K, bool TO_BASE, bool FAST, bool PRECISE = false, bool SHIFT_FREE_OK = false, int LROWS = PWL_LROWS>
 __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, const float* __restrict__ gtbl,
-                                            int L, const SplineConsts& sc, v2f& u0, v2f& u1,
+                                            int L, const SplineConsts sc, v2f& u0, v2f& u1,
                                             const PreciseConsts* pc = nullptr, const double* e2tab = nullptr,
                                             const double* tabd = nullptr, BaseAcc<v2f>* bacc = nullptr) {
   constexpr bool INV = !TO_BASE;
@@ -570,22 +572,41 @@ __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, 
       table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld);
     }
     acc += ld;
-    v2f th[PWL_P];
     bool general;
-    pwl_eval(tbl + l * PWL_LTBL, gtbl + (int64_t)l * PWL_TBL, TO_BASE ? of : uf, th, general);
+    const float* tl = tbl + l * pwl_ltbl(LROWS);
+    const float* gl = gtbl + (int64_t)l * PWL_TBL;
     if constexpr (PRECISE) {
+      v2f th[PWL_P];
+      pwl_eval<LROWS>(tl, gl, TO_BASE ? of : uf, th, general);
       cond_spline_precise<K, FAST, true>(th, uo, odd ? lo0 : lo1, sc, *pc, e2tab, oo, ld, olo_o);
       if (step == L - 1) bacc->add(oo, olo_o);
       lo0 = odd ? olo_o : olo_f;
       lo1 = odd ? olo_f : olo_o;
-#ifdef CNF_PWL_FORCE_GENERAL        /* experiment switch: never the shift-free form */
-    } else if (true) {
-#else
-    } else if (!SHIFT_FREE_OK || __builtin_amdgcn_ballot_w64(general) != 0) {      // wave-uniform: a lane's cell is marked
-#endif
-      cond_spline_masked<K, INV, FAST, false>(th, uo, sc, oo, ld);
     } else {
-      cond_spline_masked<K, INV, FAST, true>(th, uo, sc, oo, ld);
+#ifdef CNF_PWL_ROWS_OLD             /* experiment switch: all 16 logits up front, slopes selected with masks */
+      v2f th[PWL_P];
+      pwl_eval<LROWS>(tl, gl, TO_BASE ? of : uf, th, general);
+      if (!SHIFT_FREE_OK || __builtin_amdgcn_ballot_w64(general) != 0) cond_spline_masked<K, INV, FAST, false>(th, uo, sc, oo, ld);
+      else cond_spline_masked<K, INV, FAST, true>(th, uo, sc, oo, ld);
+#else
+      PwlRows rr;
+      pwl_find<LROWS>(tl, TO_BASE ? of : uf, rr, general);
+      v2f qa[K], qb[K];
+      pwl_logit_pairs<LROWS>(rr.ra, gl, rr.pa, rr.dua, qa);
+      pwl_logit_pairs<LROWS>(rr.rb, gl, rr.pb, rr.dub, qb);
+      auto slopes = [&](int ka, int kb, v2f& ta, v2f& tb) {
+        ta = pwl_slope_pair<LROWS>(rr.ra, gl, rr.pa, ka, rr.dua);
+        tb = pwl_slope_pair<LROWS>(rr.rb, gl, rr.pb, kb, rr.dub);
+      };
+#ifdef CNF_PWL_FORCE_GENERAL        /* experiment switch: never the shift-free form */
+      if (true)
+#else
+      if (!SHIFT_FREE_OK || __builtin_amdgcn_ballot_w64(general) != 0)      // wave-uniform: a lane's cell is marked
+#endif
+        cond_spline_rows<K, INV, FAST, false>(qa, qb, slopes, uo, sc, oo, ld);
+      else
+        cond_spline_rows<K, INV, FAST, true>(qa, qb, slopes, uo, sc, oo, ld);
+#endif
     }
     acc += ld;
     u0 = odd ? oo : of;
@@ -594,7 +615,7 @@ __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, 
   return acc;
 }
 
-template <int K, bool TO_BASE, bool FAST, bool PRECISE = false>
+template <int K, bool TO_BASE, bool FAST, bool PRECISE = false, int LROWS = PWL_LROWS>
 __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs a) {
   const int PWL_THREADS = blockDim.x, PWL_TS = 2 * PWL_THREADS;
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
@@ -605,11 +626,11 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
   const int L = a.m.L;
   if (gate_closed(a)) return;
   for (int i = tid; i < hdr_floats(K); i += PWL_THREADS) tab[i] = table_of<float>(a.m)[i];
-  const SplineConsts& sc = sc_of<float>(a.m);
+  const SplineConsts sc = sc_scalars(sc_of<float>(a.m));
   [[maybe_unused]] double* e2tab = nullptr;
   [[maybe_unused]] double* tabd = nullptr;
   if constexpr (PRECISE) {                 // after the L tables (HDR and PWL_LTBL are even: 8-byte aligned)
-    e2tab = reinterpret_cast<double*>(tbl + L * PWL_LTBL);
+    e2tab = reinterpret_cast<double*>(tbl + L * pwl_ltbl(LROWS));
     tabd = e2tab + EXP2_N;
     for (int i = tid; i < EXP2_N; i += PWL_THREADS) e2tab[i] = a.m.e2tab[i];
     for (int i = tid; i < hdr_floats(K); i += PWL_THREADS) tabd[i] = a.m.tabd[i];
@@ -620,11 +641,28 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
   const int t0 = blockIdx.x * per_block;
   const int t1 = t0 + per_block < total ? t0 + per_block : total;
   int cur = -1;
+  // The points of tile i + 1 are requested before tile i is computed: measured (r02e PMC) a wave spent half its
+  // time in s_waitcnt, much of it on this one load issued right in front of its first use.
+  auto tile_points = [&](int tile) {
+    const int slice = tile / a.tiles_per_slice;
+    const int64_t s0 = (int64_t)slice * a.slice_len;
+    const int64_t len = a.B - s0 < a.slice_len ? a.B - s0 : a.slice_len;
+    const int64_t j = (int64_t)(tile - slice * a.tiles_per_slice) * PWL_TS + 2 * tid;
+    const int64_t g = s0 + j;
+    f4 x = {0.f, 0.f, 0.f, 0.f};
+    if (j + 1 < len) x = *reinterpret_cast<const f4*>(a.in + 2 * g);
+    else if (j < len) { x[0] = a.in[2 * g]; x[1] = a.in[2 * g + 1]; }
+    return x;
+  };
+  [[maybe_unused]] f4 xn = {0.f, 0.f, 0.f, 0.f};
+#ifndef CNF_PWL_NO_PREFETCH
+  if (t0 < t1) xn = tile_points(t0);
+#endif
   for (int tile = t0; tile < t1; ++tile) {
     const int slice = tile / a.tiles_per_slice;
     if (slice != cur) {
       __syncthreads();
-      pwl_stage(tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, tid, PWL_THREADS);
+      pwl_stage<LROWS>(tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, tid, PWL_THREADS);
       cur = slice;
       __syncthreads();
     }
@@ -633,15 +671,19 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
     const int64_t j = (int64_t)(tile - slice * a.tiles_per_slice) * PWL_TS + 2 * tid;
     const int64_t g = s0 + j;
     const bool v0 = j < len, v1 = j + 1 < len;
-    f4 x = {0.f, 0.f, 0.f, 0.f};
-    if (v1) x = *reinterpret_cast<const f4*>(a.in + 2 * g);
-    else if (v0) { x[0] = a.in[2 * g]; x[1] = a.in[2 * g + 1]; }
+#ifdef CNF_PWL_NO_PREFETCH          /* experiment switch */
+    const f4 x = tile_points(tile);
+#else
+    const f4 x = xn;
+    if (tile + 1 < t1) xn = tile_points(tile + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     v2f u0 = {x[0], x[2]}, u1 = {x[1], x[3]};
 
     v2f base = splat<v2f>(0.0f);
     if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = (u0 * u0 + u1 * u1) * -0.5f - (float)(2 * HALF_LOG_2PI);
     BaseAcc<v2f> bacc;
-    const v2f acc = flow2_tables<K, TO_BASE, FAST, PRECISE, true>(tab, tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, sc,
+    const v2f acc = flow2_tables<K, TO_BASE, FAST, PRECISE, true, LROWS>(tab, tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, sc,
                                                             u0, u1, &a.m.scd, e2tab, tabd, &bacc);
     if (a.aux) {
       v2f r = acc;
@@ -873,7 +915,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void loss_pwl_kernel(const LossPwl
   float* tbl = lds_raw + HDR;                               // n_sets x L tables
   float* R = tbl + a.n_sets * L * PWL_LTBL;                 // 2 x TS scratch columns (potential_of / drift_of read LDS columns)
   for (int i = tid; i < hdr_floats(K); i += NT) tab[i] = table_of<float>(a.m)[i];
-  const SplineConsts& sc = sc_of<float>(a.m);
+  const SplineConsts sc = sc_scalars(sc_of<float>(a.m));
   const int kind = a.spec.kind;
   const bool kin = kind <= CNF_TERM_FLOW_MATCHING;
   const float dt = a.spec.dt, dx = a.spec.dx;
@@ -1478,8 +1520,14 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
   if (!pwl_config_ok(m)) return CNF_ERR_UNSUPPORTED;
   const int L = m->cfg.num_layers;
   const bool precise = to_base && m->precise;
-  size_t lds = (size_t)(((cnf::hdr_floats(5) + 3) & ~3) + L * cnf::PWL_LTBL) * sizeof(float) +
-               (precise ? precise_lds_bytes(5) : 0);
+  // every row of the L tables in LDS if that fits (L <= 3), else the first PWL_LROWS rows
+  auto lds_for = [&](int lrows) {
+    return (size_t)(((cnf::hdr_floats(5) + 3) & ~3) + L * cnf::pwl_ltbl(lrows)) * sizeof(float) +
+           (precise ? precise_lds_bytes(5) : 0);
+  };
+  static const int env_window = [] { const char* e = getenv("CNF_PWL_WINDOW"); return e ? atoi(e) : 0; }();   // experiment switch
+  const bool full = !env_window && lds_for(cnf::PWL_NPIECE) <= 160 * 1024;
+  size_t lds = lds_for(full ? cnf::PWL_NPIECE : cnf::PWL_LROWS);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
   const int64_t slice_len = c_block < B ? c_block : B;
   const int64_t n_slices = (B + slice_len - 1) / slice_len;
@@ -1490,8 +1538,14 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
   // Measured (MI355X, 256 x 65 536): the kernel is VALU-bound and runs best at 4 waves per SIMD -- one
   // 1024-thread workgroup per CU 58.9 G samples/s; 6 waves (3 x 512) 56.9; 2 waves 47.8.  Asking for at
   // least 82 KB of LDS keeps a second workgroup off the CU.
-  const int pwl_threads = cnf::PWL_MAX_THREADS;
-  const size_t pwl_min_lds = 82 * 1024;
+  // experiment switches (scripts/exp_occupancy.sh): CNF_PWL_THREADS = workgroup size, CNF_PWL_MIN_LDS_KB = LDS asked
+  // for per workgroup (how many workgroups share a CU)
+  static const int env_threads = [] { const char* e = getenv("CNF_PWL_THREADS"); return e ? atoi(e) : 0; }();
+  static const int env_lds_kb = [] { const char* e = getenv("CNF_PWL_MIN_LDS_KB"); return e ? atoi(e) : 0; }();
+  static const int env_bpc = [] { const char* e = getenv("CNF_PWL_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
+  const int pwl_threads = env_threads >= 64 && env_threads <= cnf::PWL_MAX_THREADS && env_threads % 64 == 0
+                              ? env_threads : cnf::PWL_MAX_THREADS;
+  const size_t pwl_min_lds = env_lds_kb > 0 ? (size_t)env_lds_kb * 1024 : 82 * 1024;
   const int64_t PWL_TS = 2 * pwl_threads;
   const int64_t tps = (slice_len + PWL_TS - 1) / PWL_TS;
   const int64_t total = n_slices * tps;
@@ -1501,10 +1555,13 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
   // (crossover with the MLP kernel: B / 26 G/s = 20 us of table building + B / 62 G/s  ->  B ~ 0.9 M samples)
   if (m->use_pwl == 1 && (total < 2 * (int64_t)m->num_cus || slice_len < 4 * PWL_TS)) return CNF_ERR_UNSUPPORTED;
   if (pwl_min_lds > lds) lds = pwl_min_lds;
-  if (precise ? !ensure_lds(cnf::flow_pwl_kernel<5, true, true, true>, lds)
-              : (to_base ? !ensure_lds(cnf::flow_pwl_kernel<5, true, true>, lds)
-                         : !ensure_lds(cnf::flow_pwl_kernel<5, false, true>, lds)))
-    return CNF_ERR_UNSUPPORTED;
+  typedef void (*PwlKernel)(const cnf::PwlArgs);
+  constexpr int ALL = cnf::PWL_NPIECE, WIN = cnf::PWL_LROWS;
+  const PwlKernel kern =
+      precise ? (full ? (PwlKernel)cnf::flow_pwl_kernel<5, true, true, true, ALL> : (PwlKernel)cnf::flow_pwl_kernel<5, true, true, true, WIN>)
+      : to_base ? (full ? (PwlKernel)cnf::flow_pwl_kernel<5, true, true, false, ALL> : (PwlKernel)cnf::flow_pwl_kernel<5, true, true, false, WIN>)
+                : (full ? (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, ALL> : (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, WIN>);
+  if (!ensure_lds(kern, lds)) return CNF_ERR_UNSUPPORTED;
   // at most PWL_MAX_SLICES slices per kernel pair: the workspace stays bounded (2 048 x L x 46 KB) however many
   // slices a call has
   int64_t chunk = n_slices < PWL_MAX_SLICES ? n_slices : PWL_MAX_SLICES;
@@ -1545,13 +1602,9 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
     a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps; a.aux_mode = aux_mode;
     a.gate = flag; a.gate_epoch = epoch; a.gate_want = 0;        // tables: only if no block stamped a difference
     const int64_t tiles = ns * tps;
-    const int64_t grid = tiles < m->num_cus ? tiles : m->num_cus;
-    if (precise)
-      hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, true, true, true>), dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
-    else if (to_base)
-      hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, true, true>), dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
-    else
-      hipLaunchKernelGGL((cnf::flow_pwl_kernel<5, false, true>), dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
+    const int64_t want = (int64_t)m->num_cus * (env_bpc > 0 ? env_bpc : 1);
+    const int64_t grid = tiles < want ? tiles : want;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
     ps.done();
   }
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;

@@ -45,6 +45,10 @@ constexpr int PWL_TBL = PWL_OFF_PIECE + PWL_NPIECE * PWL_ROW;          // floats
 // 23 KB per table instead of 46 KB: the loss kernel keeps up to three table sets of L = 2 layers in LDS.
 constexpr int PWL_LROWS = 128;
 constexpr int PWL_LTBL = PWL_OFF_PIECE + PWL_LROWS * PWL_ROW;
+// The flow kernel (one table set, L <= 3 layers) stages EVERY row instead (L x 46 KB of its 160 KB): no piece is
+// ever past the window, and the code that reads rows from the global table is not even compiled in.  The LDS
+// window is the template parameter LROWS of everything below.
+constexpr int pwl_ltbl(int lrows) { return PWL_OFF_PIECE + lrows * PWL_ROW; }
 constexpr int PWL_N_SLOT = PWL_NBP - 1;   // the piece count n, stored (as int bits) in the last padding slot of bp[]
 
 
@@ -277,10 +281,11 @@ __device__ __forceinline__ int pwl_cell(float u) {
 }
 
 // theta = S (u - u_ref) + T from row p (`gtbl`: the same table in global memory, for rows past the LDS window)
+template <int LROWS = PWL_LROWS>
 __device__ __forceinline__ void pwl_row(const float* tbl, const float* __restrict__ gtbl, int p, float u,
                                         float (&th)[PWL_P]) {
   const float du = u - tbl[PWL_OFF_REF + p];
-  if (p < PWL_LROWS) {
+  if (LROWS >= PWL_NPIECE || p < LROWS) {
     // ONE address per sample; the 8 chunks are immediate offsets of the ds_read_b128s
     const lds_f4_ptr row = (lds_f4_ptr)(uintptr_t)((uint32_t)(uintptr_t)(tbl + PWL_OFF_PIECE) + __umul24((uint32_t)p, PWL_ROW * 4));
 #pragma unroll
@@ -301,6 +306,7 @@ __device__ __forceinline__ void pwl_row(const float* tbl, const float* __restric
 }
 
 // `general`: the sample's grid cell is marked -- the spline must be evaluated the general way (pwl_build_kernel)
+template <int LROWS = PWL_LROWS>
 __device__ __forceinline__ void pwl_eval(const float* tbl, const float* __restrict__ gtbl, float u, float (&th)[PWL_P],
                                          bool& general) {
   const int g = reinterpret_cast<const int*>(tbl + PWL_OFF_GRID)[pwl_cell(u)];
@@ -308,10 +314,11 @@ __device__ __forceinline__ void pwl_eval(const float* tbl, const float* __restri
   int p = g & 0x7fffffff;
   const float us = fminf(u, 3.0e38f);            // u = +inf must stop at the +inf padding too
   while (tbl[p] <= us) ++p;                      // bp[>= n] = +inf: terminates
-  pwl_row(tbl, gtbl, p, u, th);
+  pwl_row<LROWS>(tbl, gtbl, p, u, th);
 }
 
 // Two samples: both searches advance in ONE loop (half the chain of dependent LDS reads).
+template <int LROWS = PWL_LROWS>
 __device__ __forceinline__ void pwl_eval(const float* tbl, const float* __restrict__ gtbl, v2f u, v2f (&th)[PWL_P],
                                          bool& general) {
   const int* grid = reinterpret_cast<const int*>(tbl + PWL_OFF_GRID);
@@ -327,10 +334,89 @@ __device__ __forceinline__ void pwl_eval(const float* tbl, const float* __restri
     more = mx || my;
   } while (more);
   float tx[PWL_P], ty[PWL_P];
-  pwl_row(tbl, gtbl, px, u.x, tx);
-  pwl_row(tbl, gtbl, py, u.y, ty);
+  pwl_row<LROWS>(tbl, gtbl, px, u.x, tx);
+  pwl_row<LROWS>(tbl, gtbl, py, u.y, ty);
 #pragma unroll
   for (int m = 0; m < PWL_P; ++m) th[m] = v2f{tx[m], ty[m]};
+}
+
+// --- rows evaluated in two steps (cond_spline_rows): the softmax logits as parameter pairs, then -- once the bin is
+// known -- the bin's two slope logits.  Same rows, same FMAs as pwl_row.  The LDS reads are unconditional (from a
+// clamped row for pieces past the LDS window, whose values are then replaced from the global table in a branch
+// that is almost never taken): the scheduler is free to issue them early and no lane waits inside a branch.
+typedef const float __attribute__((address_space(3))) * lds_f_ptr;
+typedef const v2f __attribute__((address_space(3))) * lds_v2_ptr;
+
+struct PwlRows {
+  int pa, pb;          // piece of sample a / b
+  float dua, dub;      // u - u_ref of the piece
+  lds_f_ptr ra, rb;    // the piece's row in LDS (row PWL_LROWS - 1 for pieces past the window)
+};
+
+template <int LROWS>
+__device__ __forceinline__ lds_f_ptr pwl_lds_row(const float* tbl, int p) {
+  const uint32_t q = LROWS >= PWL_NPIECE ? (uint32_t)p : (uint32_t)(p < LROWS ? p : LROWS - 1);
+  static_assert(PWL_ROW == 36, "row stride 144 B = 9 << 4");
+  uint32_t q9 = (q << 3) + q;                      // two full-rate shifts-and-adds instead of v_mul_lo_u32
+  asm volatile("" : "+v"(q9));
+  return (lds_f_ptr)(uintptr_t)((uint32_t)(uintptr_t)(tbl + PWL_OFF_PIECE) + (q9 << 4));
+}
+
+template <int LROWS>
+__device__ __forceinline__ void pwl_find(const float* tbl, v2f u, PwlRows& r, bool& general) {
+  const int* grid = reinterpret_cast<const int*>(tbl + PWL_OFF_GRID);
+  const int gx = grid[pwl_cell(u.x)], gy = grid[pwl_cell(u.y)];
+  general = (gx | gy) < 0;
+  int px = gx & 0x7fffffff, py = gy & 0x7fffffff;
+  const float ux = fminf(u.x, 3.0e38f), uy = fminf(u.y, 3.0e38f);
+  bool more;
+  do {
+    const bool mx = tbl[px] <= ux, my = tbl[py] <= uy;
+    px += mx ? 1 : 0;
+    py += my ? 1 : 0;
+    more = mx || my;
+  } while (more);
+  r.pa = px; r.pb = py;
+  r.dua = u.x - tbl[PWL_OFF_REF + px];
+  r.dub = u.y - tbl[PWL_OFF_REF + py];
+  r.ra = pwl_lds_row<LROWS>(tbl, px);
+  r.rb = pwl_lds_row<LROWS>(tbl, py);
+}
+
+template <class F4P, class V2P>
+__device__ __forceinline__ void pwl_logit_pairs_(F4P r4, V2P r2, float du, v2f (&q)[5]) {
+  const f4 s0 = r4[0], s1 = r4[1], t0 = r4[4], t1 = r4[5];
+  const v2f s2 = r2[4], t2 = r2[12];
+  const v2f d2 = v2f{du, du};
+  q[0] = __builtin_elementwise_fma(__builtin_shufflevector(s0, s0, 0, 1), d2, __builtin_shufflevector(t0, t0, 0, 1));
+  q[1] = __builtin_elementwise_fma(__builtin_shufflevector(s0, s0, 2, 3), d2, __builtin_shufflevector(t0, t0, 2, 3));
+  q[2] = __builtin_elementwise_fma(__builtin_shufflevector(s1, s1, 0, 1), d2, __builtin_shufflevector(t1, t1, 0, 1));
+  q[3] = __builtin_elementwise_fma(__builtin_shufflevector(s1, s1, 2, 3), d2, __builtin_shufflevector(t1, t1, 2, 3));
+  q[4] = __builtin_elementwise_fma(s2, d2, t2);
+}
+
+// the 10 softmax logits of piece p at u_ref + du, as pairs (2j, 2j+1)
+template <int LROWS>
+__device__ __forceinline__ void pwl_logit_pairs(lds_f_ptr row, const float* __restrict__ gtbl, int p, float du,
+                                                v2f (&q)[5]) {
+  pwl_logit_pairs_((lds_f4_ptr)row, (lds_v2_ptr)row, du, q);
+  if (LROWS < PWL_NPIECE && p >= LROWS) {
+    const float* g = gtbl + PWL_OFF_PIECE + p * PWL_ROW;
+    pwl_logit_pairs_(reinterpret_cast<const f4*>(g), reinterpret_cast<const v2f*>(g), du, q);
+  }
+}
+
+// (t_k, t_k+1): the slope logits of bin k's two knots (k in 0 .. 4)
+template <int LROWS>
+__device__ __forceinline__ v2f pwl_slope_pair(lds_f_ptr row, const float* __restrict__ gtbl, int p, int k, float du) {
+  const v2f d2 = v2f{du, du};
+  const lds_f_ptr r = row + k;
+  v2f t = __builtin_elementwise_fma(v2f{r[10], r[11]}, d2, v2f{r[PWL_P + 10], r[PWL_P + 11]});
+  if (LROWS < PWL_NPIECE && p >= LROWS) {
+    const float* g = gtbl + PWL_OFF_PIECE + p * PWL_ROW + k;
+    t = __builtin_elementwise_fma(v2f{g[10], g[11]}, d2, v2f{g[PWL_P + 10], g[PWL_P + 11]});
+  }
+  return t;
 }
 
 }  // namespace cnf
