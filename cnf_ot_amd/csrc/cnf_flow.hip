@@ -590,10 +590,11 @@ __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, 
       else cond_spline_masked<K, INV, FAST, true>(th, uo, sc, oo, ld);
 #else
       PwlRows rr;
-      pwl_find<LROWS>(tl, TO_BASE ? of : uf, rr, general);
+      const v2f uc = TO_BASE ? of : uf;
+      pwl_find<LROWS>(tl, uc, rr, general);
       v2f qa[K], qb[K];
-      pwl_logit_pairs<LROWS>(rr.ra, gl, rr.pa, rr.dua, qa);
-      pwl_logit_pairs<LROWS>(rr.rb, gl, rr.pb, rr.dub, qb);
+      rr.dua = pwl_logit_pairs<LROWS>(rr.ra, gl, rr.pa, uc.x, qa);
+      rr.dub = pwl_logit_pairs<LROWS>(rr.rb, gl, rr.pb, uc.y, qb);
       auto slopes = [&](int ka, int kb, v2f& ta, v2f& tb) {
         ta = pwl_slope_pair<LROWS>(rr.ra, gl, rr.pa, ka, rr.dua);
         tb = pwl_slope_pair<LROWS>(rr.rb, gl, rr.pb, kb, rr.dub);

@@ -25,14 +25,19 @@ namespace cnf {
 constexpr int PWL_H = 16;                 // hidden width this path is built for
 constexpr int PWL_P = 16;                 // spline parameters (K = 5)
 constexpr int PWL_NBP = 320;              // sorted breakpoints, +inf padded (>= 289 + sentinel)
-constexpr int PWL_NG = 512;               // coarse grid cells over [PWL_GMIN, PWL_GMAX)
+constexpr int PWL_NG = 2048;              // search grid cells over [PWL_GMIN, -PWL_GMIN), one uint16 each
 constexpr int PWL_NPIECE = 289;
 constexpr float PWL_GMIN = -16.0f;
-constexpr float PWL_GSCALE = 16.0f;       // cells per unit
+constexpr float PWL_GSCALE = 64.0f;       // cells per unit
+// grid entry: bits 0-8 the number of breakpoints <= the cell's left edge (a lower bound of the piece index),
+// bit 14: more than two breakpoints can lie below a sample of this cell (the two unrolled comparisons do not
+// finish the search), bit 15: the cell touches a piece that needs the general spline evaluation.
+constexpr uint32_t PWL_G_INDEX = 0x1ff, PWL_G_MANY = 0x4000, PWL_G_GENERAL = 0x8000;
 constexpr int PWL_NREF = 304;             // per-piece reference points (289, padded to 16 bytes)
 constexpr int PWL_OFF_GRID = PWL_NBP;
-constexpr int PWL_OFF_REF = PWL_NBP + PWL_NG;
-constexpr int PWL_OFF_PIECE = PWL_NBP + PWL_NG + PWL_NREF;
+constexpr int PWL_OFF_REF = PWL_NBP + PWL_NG / 2;
+constexpr int PWL_OFF_PIECE = PWL_NBP + PWL_NG / 2 + PWL_NREF;
+static_assert(PWL_OFF_PIECE % 4 == 0, "rows are read with 16-byte LDS loads");
 // A piece's row: 16 slopes + 16 intercepts, padded to 36 floats.  Lanes gather rows at unrelated p with
 // ds_read_b128; at a stride of 144 B consecutive rows start 4 x (9 p mod 16) banks apart, so the 64 lanes
 // spread over all LDS banks, and every chunk of a row is an immediate offset from ONE address per sample
@@ -43,7 +48,7 @@ constexpr int PWL_TBL = PWL_OFF_PIECE + PWL_NPIECE * PWL_ROW;          // floats
 // The flow and loss kernels stage the header arrays and the first PWL_LROWS rows in LDS (networks met in
 // practice have 30-50 pieces; 289 is the worst case); rows beyond that are read from the global table.
 // 23 KB per table instead of 46 KB: the loss kernel keeps up to three table sets of L = 2 layers in LDS.
-constexpr int PWL_LROWS = 128;
+constexpr int PWL_LROWS = 112;
 constexpr int PWL_LTBL = PWL_OFF_PIECE + PWL_LROWS * PWL_ROW;
 // The flow kernel (one table set, L <= 3 layers) stages EVERY row instead (L x 46 KB of its 160 KB): no piece is
 // ever past the window, and the code that reads rows from the global table is not even compiled in.  The LDS
@@ -201,7 +206,10 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
       const double nearest = lo > 0.0 ? lo : (hi < 0.0 ? hi : 0.0);
       const float uref = (float)(nearest < (double)PWL_GMIN ? (double)PWL_GMIN : (nearest > -(double)PWL_GMIN ? -(double)PWL_GMIN : nearest));
       Tt += S * (double)uref;
-      if (m == 0) { T[PWL_OFF_REF + p] = uref; urefs[pl] = (double)uref; }
+      if (m == 0) {        // also in the row's first padding slot: it then arrives with the row's own LDS reads
+        T[PWL_OFF_REF + p] = uref; urefs[pl] = (double)uref;
+        T[PWL_OFF_PIECE + p * PWL_ROW + 2 * PWL_P] = uref;
+      }
       RAW[2 * t] = S;
       RAW[2 * t + 1] = Tt;
     }
@@ -246,21 +254,25 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
     }
     __syncthreads();
   }
-  // coarse grid: number of breakpoints <= the cell's left edge (a lower bound for the scan).  The edge is
+  // search grid: number of breakpoints <= the cell's left edge (a lower bound for the search).  The edge is
   // pulled in by 1e-4: pwl_cell() computes the cell in fp32, and u a rounding error below an edge may land
-  // in the cell above it.  Sign bit: the cell touches a piece that needs the general spline evaluation, or is
-  // one of the two outermost cells (which also serve every u outside the grid).
+  // in the cell above it.  PWL_G_MANY: more than two breakpoints in (left edge, right edge] -- the kernels compare
+  // against two breakpoints unconditionally and loop only in such cells (cell 0 / the last cell also serve every
+  // u beyond the grid).  PWL_G_GENERAL: the cell touches a piece that needs the general spline evaluation, or is
+  // one of the two outermost cells.
   for (int g = tid; g < PWL_NG; g += blockDim.x) {
     const double x = (double)PWL_GMIN + (double)g / (double)PWL_GSCALE - 1e-4;
-    int lo_ = 0, hi_ = g == 0 ? 0 : n;          // cell 0 also serves every u below the grid: scan from piece 0
+    int lo_ = 0, hi_ = g == 0 ? 0 : n;          // cell 0 also serves every u below the grid: search from piece 0
     while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (cand[mid] <= x) lo_ = mid + 1; else hi_ = mid; }
-    const double xr = (double)PWL_GMIN + (double)(g + 1) / (double)PWL_GSCALE + 1e-4;
+    const double xr = g == PWL_NG - 1 ? INF : (double)PWL_GMIN + (double)(g + 1) / (double)PWL_GSCALE + 1e-4;
     int mark = (g == 0 || g == PWL_NG - 1) ? 1 : 0;
     for (int p = lo_; p <= n && !mark; ++p) {          // pieces lo_ .. the one holding the cell's right edge
       mark |= bad[p];
       if (p < n && cand[p] > xr) break;
     }
-    reinterpret_cast<int*>(T + PWL_OFF_GRID)[g] = lo_ | (mark ? (int)0x80000000 : 0);
+    const bool many = lo_ + 2 < n && cand[lo_ + 2] <= xr;      // a third breakpoint a sample of the cell can pass
+    reinterpret_cast<uint16_t*>(T + PWL_OFF_GRID)[g] =
+        (uint16_t)((uint32_t)lo_ | (mark ? PWL_G_GENERAL : 0u) | (many ? PWL_G_MANY : 0u));
   }
 }
 
@@ -306,33 +318,52 @@ __device__ __forceinline__ void pwl_row(const float* tbl, const float* __restric
 }
 
 // `general`: the sample's grid cell is marked -- the spline must be evaluated the general way (pwl_build_kernel)
+// Piece of u: grid lookup, two unrolled comparisons, and a loop only where the builder found more than two
+// breakpoints in reach of the cell.
+__device__ __forceinline__ int pwl_piece(const float* tbl, float u, bool& general) {
+  const uint32_t g = reinterpret_cast<const uint16_t*>(tbl + PWL_OFF_GRID)[pwl_cell(u)];
+  general = (g & PWL_G_GENERAL) != 0;
+  int p = (int)(g & PWL_G_INDEX);
+  const float us = fminf(u, 3.0e38f);            // u = +inf must stop at the +inf padding too
+  const float b0 = tbl[p], b1 = tbl[p + 1];      // sorted: b1 <= us implies b0 <= us
+  p += (b0 <= us ? 1 : 0) + (b1 <= us ? 1 : 0);
+  if (g & PWL_G_MANY) while (tbl[p] <= us) ++p;  // bp[>= n] = +inf: terminates
+  return p;
+}
+// Two samples: one wave-level branch for the rare loop.
+__device__ __forceinline__ void pwl_piece(const float* tbl, v2f u, int& px, int& py, bool& general) {
+  const uint16_t* grid = reinterpret_cast<const uint16_t*>(tbl + PWL_OFF_GRID);
+  const uint32_t gx = grid[pwl_cell(u.x)], gy = grid[pwl_cell(u.y)];
+  general = ((gx | gy) & PWL_G_GENERAL) != 0;
+  px = (int)(gx & PWL_G_INDEX); py = (int)(gy & PWL_G_INDEX);
+  const float ux = fminf(u.x, 3.0e38f), uy = fminf(u.y, 3.0e38f);
+  const float ax0 = tbl[px], ax1 = tbl[px + 1], ay0 = tbl[py], ay1 = tbl[py + 1];
+  px += (ax0 <= ux ? 1 : 0) + (ax1 <= ux ? 1 : 0);
+  py += (ay0 <= uy ? 1 : 0) + (ay1 <= uy ? 1 : 0);
+  if ((gx | gy) & PWL_G_MANY) {
+    bool more;
+    do {
+      const bool mx = tbl[px] <= ux, my = tbl[py] <= uy;
+      px += mx ? 1 : 0;
+      py += my ? 1 : 0;
+      more = mx || my;
+    } while (more);
+  }
+}
+
+// `general`: the sample's grid cell is marked -- the spline must be evaluated the general way (pwl_build_kernel)
 template <int LROWS = PWL_LROWS>
 __device__ __forceinline__ void pwl_eval(const float* tbl, const float* __restrict__ gtbl, float u, float (&th)[PWL_P],
                                          bool& general) {
-  const int g = reinterpret_cast<const int*>(tbl + PWL_OFF_GRID)[pwl_cell(u)];
-  general = g < 0;
-  int p = g & 0x7fffffff;
-  const float us = fminf(u, 3.0e38f);            // u = +inf must stop at the +inf padding too
-  while (tbl[p] <= us) ++p;                      // bp[>= n] = +inf: terminates
+  const int p = pwl_piece(tbl, u, general);
   pwl_row<LROWS>(tbl, gtbl, p, u, th);
 }
 
-// Two samples: both searches advance in ONE loop (half the chain of dependent LDS reads).
 template <int LROWS = PWL_LROWS>
 __device__ __forceinline__ void pwl_eval(const float* tbl, const float* __restrict__ gtbl, v2f u, v2f (&th)[PWL_P],
                                          bool& general) {
-  const int* grid = reinterpret_cast<const int*>(tbl + PWL_OFF_GRID);
-  const int gx = grid[pwl_cell(u.x)], gy = grid[pwl_cell(u.y)];
-  general = (gx | gy) < 0;
-  int px = gx & 0x7fffffff, py = gy & 0x7fffffff;
-  const float ux = fminf(u.x, 3.0e38f), uy = fminf(u.y, 3.0e38f);
-  bool more;
-  do {
-    const bool mx = tbl[px] <= ux, my = tbl[py] <= uy;
-    px += mx ? 1 : 0;
-    py += my ? 1 : 0;
-    more = mx || my;
-  } while (more);
+  int px, py;
+  pwl_piece(tbl, u, px, py, general);
   float tx[PWL_P], ty[PWL_P];
   pwl_row<LROWS>(tbl, gtbl, px, u.x, tx);
   pwl_row<LROWS>(tbl, gtbl, py, u.y, ty);
@@ -349,8 +380,8 @@ typedef const v2f __attribute__((address_space(3))) * lds_v2_ptr;
 
 struct PwlRows {
   int pa, pb;          // piece of sample a / b
-  float dua, dub;      // u - u_ref of the piece
-  lds_f_ptr ra, rb;    // the piece's row in LDS (row PWL_LROWS - 1 for pieces past the window)
+  float dua, dub;      // u - u_ref of the piece (set by pwl_logit_pairs: u_ref is read with the row)
+  lds_f_ptr ra, rb;    // the piece's row in LDS (row LROWS - 1 for pieces past the window)
 };
 
 template <int LROWS>
@@ -364,46 +395,37 @@ __device__ __forceinline__ lds_f_ptr pwl_lds_row(const float* tbl, int p) {
 
 template <int LROWS>
 __device__ __forceinline__ void pwl_find(const float* tbl, v2f u, PwlRows& r, bool& general) {
-  const int* grid = reinterpret_cast<const int*>(tbl + PWL_OFF_GRID);
-  const int gx = grid[pwl_cell(u.x)], gy = grid[pwl_cell(u.y)];
-  general = (gx | gy) < 0;
-  int px = gx & 0x7fffffff, py = gy & 0x7fffffff;
-  const float ux = fminf(u.x, 3.0e38f), uy = fminf(u.y, 3.0e38f);
-  bool more;
-  do {
-    const bool mx = tbl[px] <= ux, my = tbl[py] <= uy;
-    px += mx ? 1 : 0;
-    py += my ? 1 : 0;
-    more = mx || my;
-  } while (more);
+  int px, py;
+  pwl_piece(tbl, u, px, py, general);
   r.pa = px; r.pb = py;
-  r.dua = u.x - tbl[PWL_OFF_REF + px];
-  r.dub = u.y - tbl[PWL_OFF_REF + py];
   r.ra = pwl_lds_row<LROWS>(tbl, px);
   r.rb = pwl_lds_row<LROWS>(tbl, py);
 }
 
-template <class F4P, class V2P>
-__device__ __forceinline__ void pwl_logit_pairs_(F4P r4, V2P r2, float du, v2f (&q)[5]) {
+template <class FP, class F4P, class V2P>
+__device__ __forceinline__ float pwl_logit_pairs_(FP r, F4P r4, V2P r2, float u, v2f (&q)[5]) {
   const f4 s0 = r4[0], s1 = r4[1], t0 = r4[4], t1 = r4[5];
   const v2f s2 = r2[4], t2 = r2[12];
+  const float du = u - r[2 * PWL_P];
   const v2f d2 = v2f{du, du};
   q[0] = __builtin_elementwise_fma(__builtin_shufflevector(s0, s0, 0, 1), d2, __builtin_shufflevector(t0, t0, 0, 1));
   q[1] = __builtin_elementwise_fma(__builtin_shufflevector(s0, s0, 2, 3), d2, __builtin_shufflevector(t0, t0, 2, 3));
   q[2] = __builtin_elementwise_fma(__builtin_shufflevector(s1, s1, 0, 1), d2, __builtin_shufflevector(t1, t1, 0, 1));
   q[3] = __builtin_elementwise_fma(__builtin_shufflevector(s1, s1, 2, 3), d2, __builtin_shufflevector(t1, t1, 2, 3));
   q[4] = __builtin_elementwise_fma(s2, d2, t2);
+  return du;
 }
 
-// the 10 softmax logits of piece p at u_ref + du, as pairs (2j, 2j+1)
+// the 10 softmax logits of piece p at u, as pairs (2j, 2j+1); returns u - u_ref
 template <int LROWS>
-__device__ __forceinline__ void pwl_logit_pairs(lds_f_ptr row, const float* __restrict__ gtbl, int p, float du,
-                                                v2f (&q)[5]) {
-  pwl_logit_pairs_((lds_f4_ptr)row, (lds_v2_ptr)row, du, q);
+__device__ __forceinline__ float pwl_logit_pairs(lds_f_ptr row, const float* __restrict__ gtbl, int p, float u,
+                                                 v2f (&q)[5]) {
+  float du = pwl_logit_pairs_(row, (lds_f4_ptr)row, (lds_v2_ptr)row, u, q);
   if (LROWS < PWL_NPIECE && p >= LROWS) {
     const float* g = gtbl + PWL_OFF_PIECE + p * PWL_ROW;
-    pwl_logit_pairs_(reinterpret_cast<const f4*>(g), reinterpret_cast<const v2f*>(g), du, q);
+    du = pwl_logit_pairs_(g, reinterpret_cast<const f4*>(g), reinterpret_cast<const v2f*>(g), u, q);
   }
+  return du;
 }
 
 // (t_k, t_k+1): the slope logits of bin k's two knots (k in 0 .. 4)
