@@ -254,7 +254,9 @@ __device__ __forceinline__ T knot_slope(T t, const SplineConstsT<typename Lanes<
 // c = -s w with w = (v - y0) / bh) scaled through by bh -- the root does not
 // change and 1 / bh is never needed.  L2S_GIVEN: 2 log s comes from the caller
 // (the prepared table); otherwise it is folded into the one logarithm.
-template <bool INV, bool FAST, class T, bool L2S_GIVEN = true>
+// ARG: `ld` receives the ARGUMENT of that logarithm (the spline's derivative f'), not +-log of it: a caller that
+// evaluates several splines multiplies the arguments and takes one logarithm.
+template <bool INV, bool FAST, class T, bool L2S_GIVEN = true, bool ARG = false>
 __device__ __forceinline__ void rqs_bin_eval(T v, T x0, T y0, T bw, T bh, T ibw, T s, T st,
                                              T d0, T d1, T l2s, T& out, T& ld) {
   using M = Math<FAST>;
@@ -278,14 +280,20 @@ __device__ __forceinline__ void rqs_bin_eval(T v, T x0, T y0, T bw, T bh, T ibw,
   if (!INV) out = vfma(bh * vfma(s, sq_z, d0 * z1mz), iden, y0);
   const T num2 = vfma(d1, sq_z, vfma(s * 2.0f, z1mz, d0 * omz * omz));
   // 2 log s + log(num2) - 2 log(den)
-  T ldf;
-  if (L2S_GIVEN) {
-    ldf = l2s + M::log(num2 * iden * iden);
-  } else {
+  if constexpr (ARG) {
+    static_assert(!L2S_GIVEN, "the argument form folds s^2 in");
     const T q = s * iden;
-    ldf = M::log(num2 * q * q);
+    ld = num2 * q * q;
+  } else {
+    T ldf;
+    if (L2S_GIVEN) {
+      ldf = l2s + M::log(num2 * iden * iden);
+    } else {
+      const T q = s * iden;
+      ldf = M::log(num2 * q * q);
+    }
+    ld = INV ? -ldf : ldf;
   }
-  ld = INV ? -ldf : ldf;
 }
 
 // ---------------------------------------------------------------------------
@@ -344,7 +352,7 @@ template <> struct BinRow<v2f> {
   template <int K> __device__ __forceinline__ v2f get(int f) const { return v2f{px[tab_off(f, K)], py[tab_off(f, K)]}; }
 };
 
-template <int K, bool INV, bool FAST, class T>
+template <int K, bool INV, bool FAST, class T, bool ARG = false>
 __device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab, T v,
                                              const SplineConstsT<typename Lanes<T>::real> sc, T& out, T& ld) {
   typedef typename Lanes<T>::real R;
@@ -352,10 +360,19 @@ __device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab,
   if constexpr (std::is_same<T, v2f>::value) k = bin_of_pairs<K>(tab + tab_off(INV ? F_YKB : F_XKB, K), v);
   else k = bin_of<K>(tab + tab_off(INV ? F_YK : F_XK, K), v);
   const BinRow<T> row(tab, k);
-  rqs_bin_eval<INV, FAST, T>(v, row.template get<K>(F_X0), row.template get<K>(F_Y0), row.template get<K>(F_BW),
-                             row.template get<K>(F_BH), row.template get<K>(F_IBW),
-                             row.template get<K>(F_S), row.template get<K>(F_ST), row.template get<K>(F_D0),
-                             row.template get<K>(F_D1), row.template get<K>(F_L2S), out, ld);
+  // (the pair rows are read through volatile pointers: a field the direction does not use must not be asked for)
+  const T bw = INV ? row.template get<K>(F_BW) : splat<T>(0.0f);          // the inverse never divides by bw ...
+  const T ibw = INV ? splat<T>(0.0f) : row.template get<K>(F_IBW);        // ... the forward map only does
+  if constexpr (ARG)
+    rqs_bin_eval<INV, FAST, T, false, true>(v, row.template get<K>(F_X0), row.template get<K>(F_Y0), bw,
+                                            row.template get<K>(F_BH), ibw,
+                                            row.template get<K>(F_S), row.template get<K>(F_ST), row.template get<K>(F_D0),
+                                            row.template get<K>(F_D1), splat<T>(0.0f), out, ld);
+  else
+    rqs_bin_eval<INV, FAST, T>(v, row.template get<K>(F_X0), row.template get<K>(F_Y0), bw,
+                               row.template get<K>(F_BH), ibw,
+                               row.template get<K>(F_S), row.template get<K>(F_ST), row.template get<K>(F_D0),
+                               row.template get<K>(F_D1), row.template get<K>(F_L2S), out, ld);
   if (maybe_outside(v, sc.lo, sc.hi)) {   // linear tails (rare: |v| >= 10)
     const auto below = vle(v, sc.lo);
     const auto above = vge(v, sc.hi);
@@ -365,9 +382,9 @@ __device__ __forceinline__ void table_spline(const typename Lanes<T>::real* tab,
     const T hi_out = INV ? vfma(v - sc.hi, splat<T>(tl[T_INV_DHI]), splat<T>(sc.hi))
                          : vfma(v - sc.hi, splat<T>(tl[T_DHI]), splat<T>(sc.hi));
     out = vsel(below, lo_out, out);
-    ld = vsel(below, splat<T>(INV ? -tl[T_LOG_DLO] : tl[T_LOG_DLO]), ld);
+    ld = vsel(below, ARG ? splat<T>(tl[T_DLO]) : splat<T>(INV ? -tl[T_LOG_DLO] : tl[T_LOG_DLO]), ld);
     out = vsel(above, hi_out, out);
-    ld = vsel(above, splat<T>(INV ? -tl[T_LOG_DHI] : tl[T_LOG_DHI]), ld);
+    ld = vsel(above, ARG ? splat<T>(tl[T_DHI]) : splat<T>(INV ? -tl[T_LOG_DHI] : tl[T_LOG_DHI]), ld);
   }
 }
 
@@ -485,7 +502,7 @@ __device__ __forceinline__ void cond_spline_masked(const v2f (&th)[3 * K + 1], v
 // The slope logits are not evaluated for all K + 1 knots and then selected with masks: the bin index (the sum of
 // the 0/1 masks) addresses the row a second time and `slopes(ka, kb, ta, tb)` returns (t_k, t_k+1) of each sample
 // from one packed FMA.  Same values bit for bit as cond_spline_masked on the same rows.
-template <int K, bool INV, bool FAST, bool SHIFT_FREE, class SlopeFetch>
+template <int K, bool INV, bool FAST, bool SHIFT_FREE, bool ARG = false, class SlopeFetch>
 __device__ __forceinline__ void cond_spline_rows(const v2f (&qa)[K], const v2f (&qb)[K], SlopeFetch&& slopes, v2f v,
                                                  const SplineConsts sc, v2f& out, v2f& ld) {
   using M = Math<FAST>;
@@ -562,17 +579,22 @@ __device__ __forceinline__ void cond_spline_rows(const v2f (&qa)[K], const v2f (
   const T ibw = M::rcp(bw);
   const T s = bh * ibw;
   const T st = d1 + d0 - s * 2.0f;
-  rqs_bin_eval<INV, FAST, T, false>(v, x0, y0, bw, bh, ibw, s, st, d0, d1, s, out, ld);
+  rqs_bin_eval<INV, FAST, T, false, ARG>(v, x0, y0, bw, bh, ibw, s, st, d0, d1, s, out, ld);
   if (maybe_outside(v, sc.lo, sc.hi)) {
     const auto below = vle(v, sc.lo);          // bin 0 was selected: d0 = slope[0]
     const auto above = vge(v, sc.hi);          // bin K-1 was selected: d1 = slope[K]
     const T lo_out = INV ? M::div(v - sc.lo, d0) + sc.lo : vfma(v - sc.lo, d0, splat<T>(sc.lo));
     const T hi_out = INV ? M::div(v - sc.hi, d1) + sc.hi : vfma(v - sc.hi, d1, splat<T>(sc.hi));
-    const T ld0 = M::log(d0), ld1 = M::log(d1);
     out = vsel(below, lo_out, out);
-    ld = vsel(below, INV ? -ld0 : ld0, ld);
     out = vsel(above, hi_out, out);
-    ld = vsel(above, INV ? -ld1 : ld1, ld);
+    if constexpr (ARG) {
+      ld = vsel(below, d0, ld);
+      ld = vsel(above, d1, ld);
+    } else {
+      const T ld0 = M::log(d0), ld1 = M::log(d1);
+      ld = vsel(below, INV ? -ld0 : ld0, ld);
+      ld = vsel(above, INV ? -ld1 : ld1, ld);
+    }
   }
 }
 

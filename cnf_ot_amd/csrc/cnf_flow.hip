@@ -551,7 +551,10 @@ __device__ __forceinline__ void pwl_stage(float* tbl, const float* __restrict__ 
 // returns the accumulated log|det J| of the direction.
 // SHIFT_FREE_OK: use the shift-free spline evaluation where the sample's grid cell allows it (the flow kernels;
 // the loss kernel, at its register limit with three table sets, always evaluates the general form).
-template <int K, bool TO_BASE, bool FAST, bool PRECISE = false, bool SHIFT_FREE_OK = false, int LROWS = PWL_LROWS>
+// LFIX > 0: the number of flow layers is this compile-time constant -- the layer loop is unrolled, the layer's
+// parity (which coordinate is conditioned on which) and its table's LDS offset are literals instead of per-layer
+// selects and address arithmetic.
+template <int K, bool TO_BASE, bool FAST, bool PRECISE = false, bool SHIFT_FREE_OK = false, int LROWS = PWL_LROWS, int LFIX = 0>
 __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, const float* __restrict__ gtbl,
                                             int L, const SplineConsts sc, v2f& u0, v2f& u1,
                                             const PreciseConsts* pc = nullptr, const double* e2tab = nullptr,
@@ -560,41 +563,65 @@ __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, 
   static_assert(!PRECISE || TO_BASE, "precise path: data -> base");
   v2f acc = splat<v2f>(0.0f);
   [[maybe_unused]] v2f lo0 = splat<v2f>(0.0f), lo1 = lo0;      // precise path: what rounding u0 / u1 to fp32 dropped
-  for (int step = 0; step < L; ++step) {
+  if (LFIX) L = LFIX;
+#pragma unroll
+  for (int step = 0; step < (LFIX ? LFIX : L); ++step) {
     const int l = TO_BASE ? L - 1 - step : step;
     const bool odd = l & 1;                     // flows.py:141-143 perms
     const v2f uf = odd ? u1 : u0, uo = odd ? u0 : u1;
     v2f of, oo, ld, olo_f, olo_o;
-    if constexpr (PRECISE) {
-      table_spline_precise<K, FAST>(tab, tabd, uf, odd ? lo1 : lo0, sc, of, ld, olo_f);
-      if (step == L - 1) bacc->add(of, olo_f);
-    } else {
-      table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld);
-    }
-    acc += ld;
     bool general;
     const float* tl = tbl + l * pwl_ltbl(LROWS);
     const float* gl = gtbl + (int64_t)l * PWL_TBL;
     if constexpr (PRECISE) {
+      table_spline_precise<K, FAST>(tab, tabd, uf, odd ? lo1 : lo0, sc, of, ld, olo_f);
+      if (step == L - 1) bacc->add(of, olo_f);
+      acc += ld;
       v2f th[PWL_P];
-      pwl_eval<LROWS>(tl, gl, TO_BASE ? of : uf, th, general);
+      pwl_eval<LROWS>(tl, gl, of, th, general);
       cond_spline_precise<K, FAST, true>(th, uo, odd ? lo0 : lo1, sc, *pc, e2tab, oo, ld, olo_o);
       if (step == L - 1) bacc->add(oo, olo_o);
       lo0 = odd ? olo_o : olo_f;
       lo1 = odd ? olo_f : olo_o;
     } else {
 #ifdef CNF_PWL_ROWS_OLD             /* experiment switch: all 16 logits up front, slopes selected with masks */
+      table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld);
+      acc += ld;
       v2f th[PWL_P];
       pwl_eval<LROWS>(tl, gl, TO_BASE ? of : uf, th, general);
       if (!SHIFT_FREE_OK || __builtin_amdgcn_ballot_w64(general) != 0) cond_spline_masked<K, INV, FAST, false>(th, uo, sc, oo, ld);
       else cond_spline_masked<K, INV, FAST, true>(th, uo, sc, oo, ld);
 #else
+      // base -> data: the conditioner sees the layer's INPUT, so its table search and row reads (a chain of three
+      // dependent LDS round trips) are issued first and complete under the arithmetic of the `first` spline
       PwlRows rr;
-      const v2f uc = TO_BASE ? of : uf;
-      pwl_find<LROWS>(tl, uc, rr, general);
       v2f qa[K], qb[K];
-      rr.dua = pwl_logit_pairs<LROWS>(rr.ra, gl, rr.pa, uc.x, qa);
-      rr.dub = pwl_logit_pairs<LROWS>(rr.rb, gl, rr.pb, uc.y, qb);
+      if (!TO_BASE) {
+        pwl_find<LROWS>(tl, uf, rr, general);
+        rr.dua = pwl_logit_pairs<LROWS>(rr.ra, gl, rr.pa, uf.x, qa);
+        rr.dub = pwl_logit_pairs<LROWS>(rr.rb, gl, rr.pb, uf.y, qb);
+      }
+      // One logarithm per layer where every lane takes the shift-free form: both splines return the argument of
+      // their log|f'| (the derivative itself) and the product goes through one v_log_f32.  The conditioned
+      // factor is bounded there (slope logits in [-3, 40], bins >= 1e-4 of a range of 20: ~1e-9 .. 1e6), so the
+      // product leaves the fp32 range only for a `first` spline with derivatives beyond 1e-29 .. 1e32.
+#ifdef CNF_PWL_LOGPROD              /* experiment switch: measured within noise (1.477 vs 1.480 ms), off */
+      constexpr bool LOGPROD = SHIFT_FREE_OK;
+#else
+      constexpr bool LOGPROD = false;
+#endif
+      v2f larg = splat<v2f>(1.0f);
+      if constexpr (LOGPROD) {
+        table_spline<K, INV, FAST, v2f, true>(tab, uf, sc, of, larg);
+      } else {
+        table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld);
+        acc += ld;
+      }
+      if (TO_BASE) {
+        pwl_find<LROWS>(tl, of, rr, general);
+        rr.dua = pwl_logit_pairs<LROWS>(rr.ra, gl, rr.pa, of.x, qa);
+        rr.dub = pwl_logit_pairs<LROWS>(rr.rb, gl, rr.pb, of.y, qb);
+      }
       auto slopes = [&](int ka, int kb, v2f& ta, v2f& tb) {
         ta = pwl_slope_pair<LROWS>(rr.ra, gl, rr.pa, ka, rr.dua);
         tb = pwl_slope_pair<LROWS>(rr.rb, gl, rr.pb, kb, rr.dub);
@@ -604,9 +631,13 @@ __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, 
 #else
       if (!SHIFT_FREE_OK || __builtin_amdgcn_ballot_w64(general) != 0)      // wave-uniform: a lane's cell is marked
 #endif
-        cond_spline_rows<K, INV, FAST, false>(qa, qb, slopes, uo, sc, oo, ld);
-      else
-        cond_spline_rows<K, INV, FAST, true>(qa, qb, slopes, uo, sc, oo, ld);
+      {       // marked cells (ill-conditioned pieces, far-out inputs): the general form, and its own logarithm
+        cond_spline_rows<K, INV, FAST, false, false>(qa, qb, slopes, uo, sc, oo, ld);
+        if constexpr (LOGPROD) { const v2f lg = Math<FAST>::log(larg); ld += INV ? -lg : lg; }
+      } else {
+        cond_spline_rows<K, INV, FAST, true, LOGPROD>(qa, qb, slopes, uo, sc, oo, ld);
+        if constexpr (LOGPROD) { const v2f lg = Math<FAST>::log(larg * ld); ld = INV ? -lg : lg; }
+      }
 #endif
     }
     acc += ld;
@@ -616,7 +647,7 @@ __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, 
   return acc;
 }
 
-template <int K, bool TO_BASE, bool FAST, bool PRECISE = false, int LROWS = PWL_LROWS>
+template <int K, bool TO_BASE, bool FAST, bool PRECISE = false, int LROWS = PWL_LROWS, int LFIX = 0>
 __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs a) {
   const int PWL_THREADS = blockDim.x, PWL_TS = 2 * PWL_THREADS;
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
@@ -624,7 +655,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
   float* tab = lds_raw;
   float* tbl = lds_raw + HDR;
   const int tid = threadIdx.x;
-  const int L = a.m.L;
+  const int L = LFIX ? LFIX : a.m.L;
   if (gate_closed(a)) return;
   for (int i = tid; i < hdr_floats(K); i += PWL_THREADS) tab[i] = table_of<float>(a.m)[i];
   const SplineConsts sc = sc_scalars(sc_of<float>(a.m));
@@ -642,41 +673,52 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
   const int t0 = blockIdx.x * per_block;
   const int t1 = t0 + per_block < total ? t0 + per_block : total;
   int cur = -1;
-  // The points of tile i + 1 are requested before tile i is computed: measured (r02e PMC) a wave spent half its
-  // time in s_waitcnt, much of it on this one load issued right in front of its first use.
-  auto tile_points = [&](int tile) {
-    const int slice = tile / a.tiles_per_slice;
-    const int64_t s0 = (int64_t)slice * a.slice_len;
+  // Tile geometry is wave-uniform (scalar registers): the slice, the tile's first sample and how many of its
+  // PWL_TS samples exist.  A lane's share is then a 32-bit offset from a scalar base address, and a full tile
+  // -- every tile but the last of a slice of odd size -- takes the unmasked path.
+  struct Tile { int slice; int valid; int64_t g0; };
+  auto tile_of = [&](int tile) {
+    Tile t;
+    t.slice = tile / a.tiles_per_slice;
+    const int64_t s0 = (int64_t)t.slice * a.slice_len;
     const int64_t len = a.B - s0 < a.slice_len ? a.B - s0 : a.slice_len;
-    const int64_t j = (int64_t)(tile - slice * a.tiles_per_slice) * PWL_TS + 2 * tid;
-    const int64_t g = s0 + j;
+    const int64_t jt = (int64_t)(tile - t.slice * a.tiles_per_slice) * PWL_TS;
+    const int64_t left = len - jt;
+    t.valid = left >= PWL_TS ? PWL_TS : (left > 0 ? (int)left : 0);
+    t.g0 = s0 + jt;
+    return t;
+  };
+  const uint32_t lane2 = 2u * (uint32_t)tid;             // the lane's first sample within the tile
+  auto tile_points = [&](const Tile& t) {
+    const float* p = a.in + 2 * t.g0;
     f4 x = {0.f, 0.f, 0.f, 0.f};
-    if (j + 1 < len) x = *reinterpret_cast<const f4*>(a.in + 2 * g);
-    else if (j < len) { x[0] = a.in[2 * g]; x[1] = a.in[2 * g + 1]; }
+    if (t.valid == PWL_TS) x = *reinterpret_cast<const f4*>(p + 2u * lane2);
+    else if ((int)lane2 + 1 < t.valid) x = *reinterpret_cast<const f4*>(p + 2u * lane2);
+    else if ((int)lane2 < t.valid) { x[0] = p[2u * lane2]; x[1] = p[2u * lane2 + 1]; }
     return x;
   };
+  // The points of tile i + 1 are requested before tile i is computed: measured (r02e PMC) a wave spent half its
+  // time in s_waitcnt, much of it on this one load issued right in front of its first use.
   [[maybe_unused]] f4 xn = {0.f, 0.f, 0.f, 0.f};
 #ifndef CNF_PWL_NO_PREFETCH
-  if (t0 < t1) xn = tile_points(t0);
+  if (t0 < t1) xn = tile_points(tile_of(t0));
 #endif
   for (int tile = t0; tile < t1; ++tile) {
-    const int slice = tile / a.tiles_per_slice;
+    const Tile tl = tile_of(tile);
+    const int slice = tl.slice;
     if (slice != cur) {
       __syncthreads();
       pwl_stage<LROWS>(tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, tid, PWL_THREADS);
       cur = slice;
       __syncthreads();
     }
-    const int64_t s0 = (int64_t)slice * a.slice_len;
-    const int64_t len = a.B - s0 < a.slice_len ? a.B - s0 : a.slice_len;
-    const int64_t j = (int64_t)(tile - slice * a.tiles_per_slice) * PWL_TS + 2 * tid;
-    const int64_t g = s0 + j;
-    const bool v0 = j < len, v1 = j + 1 < len;
+    const bool full = tl.valid == PWL_TS;
+    const bool v0 = (int)lane2 < tl.valid, v1 = (int)lane2 + 1 < tl.valid;
 #ifdef CNF_PWL_NO_PREFETCH          /* experiment switch */
-    const f4 x = tile_points(tile);
+    const f4 x = tile_points(tl);
 #else
     const f4 x = xn;
-    if (tile + 1 < t1) xn = tile_points(tile + 1);
+    if (tile + 1 < t1) xn = tile_points(tile_of(tile + 1));
     __builtin_amdgcn_sched_barrier(0);
 #endif
     v2f u0 = {x[0], x[2]}, u1 = {x[1], x[3]};
@@ -684,19 +726,21 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
     v2f base = splat<v2f>(0.0f);
     if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = (u0 * u0 + u1 * u1) * -0.5f - (float)(2 * HALF_LOG_2PI);
     BaseAcc<v2f> bacc;
-    const v2f acc = flow2_tables<K, TO_BASE, FAST, PRECISE, true, LROWS>(tab, tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, sc,
+    const v2f acc = flow2_tables<K, TO_BASE, FAST, PRECISE, true, LROWS, LFIX>(tab, tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, sc,
                                                             u0, u1, &a.m.scd, e2tab, tabd, &bacc);
     if (a.aux) {
       v2f r = acc;
       if constexpr (PRECISE) { if (a.aux_mode == AUX_LOGPROB) r = bacc.log_prob(acc, 2); }
       else if (a.aux_mode == AUX_LOGPROB)
         r = TO_BASE ? (u0 * u0 + u1 * u1) * -0.5f - (float)(2 * HALF_LOG_2PI) + acc : base - acc;
-      if (v1) *reinterpret_cast<v2f*>(a.aux + g) = r;
-      else if (v0) a.aux[g] = r.x;
+      float* q = a.aux + tl.g0;
+      if (full || v1) *reinterpret_cast<v2f*>(q + lane2) = r;
+      else if (v0) q[lane2] = r.x;
     }
     if (a.out) {
-      if (v1) *reinterpret_cast<f4*>(a.out + 2 * g) = f4{u0.x, u1.x, u0.y, u1.y};
-      else if (v0) { a.out[2 * g] = u0.x; a.out[2 * g + 1] = u1.x; }
+      float* q = a.out + 2 * tl.g0;
+      if (full || v1) *reinterpret_cast<f4*>(q + 2u * lane2) = f4{u0.x, u1.x, u0.y, u1.y};
+      else if (v0) { q[2u * lane2] = u0.x; q[2u * lane2 + 1] = u1.x; }
     }
   }
 }
@@ -1558,10 +1602,15 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
   if (pwl_min_lds > lds) lds = pwl_min_lds;
   typedef void (*PwlKernel)(const cnf::PwlArgs);
   constexpr int ALL = cnf::PWL_NPIECE, WIN = cnf::PWL_LROWS;
+  // L = 2 (every configuration of the reference) has its own instantiation with the layer loop unrolled
+  const bool l2 = full && L == 2;
   const PwlKernel kern =
-      precise ? (full ? (PwlKernel)cnf::flow_pwl_kernel<5, true, true, true, ALL> : (PwlKernel)cnf::flow_pwl_kernel<5, true, true, true, WIN>)
-      : to_base ? (full ? (PwlKernel)cnf::flow_pwl_kernel<5, true, true, false, ALL> : (PwlKernel)cnf::flow_pwl_kernel<5, true, true, false, WIN>)
-                : (full ? (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, ALL> : (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, WIN>);
+      precise ? (l2 ? (PwlKernel)cnf::flow_pwl_kernel<5, true, true, true, ALL, 2>
+                    : full ? (PwlKernel)cnf::flow_pwl_kernel<5, true, true, true, ALL> : (PwlKernel)cnf::flow_pwl_kernel<5, true, true, true, WIN>)
+      : to_base ? (l2 ? (PwlKernel)cnf::flow_pwl_kernel<5, true, true, false, ALL, 2>
+                      : full ? (PwlKernel)cnf::flow_pwl_kernel<5, true, true, false, ALL> : (PwlKernel)cnf::flow_pwl_kernel<5, true, true, false, WIN>)
+                : (l2 ? (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, ALL, 2>
+                      : full ? (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, ALL> : (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, WIN>);
   if (!ensure_lds(kern, lds)) return CNF_ERR_UNSUPPORTED;
   // at most PWL_MAX_SLICES slices per kernel pair: the workspace stays bounded (2 048 x L x 46 KB) however many
   // slices a call has

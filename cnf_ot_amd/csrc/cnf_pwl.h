@@ -24,7 +24,7 @@ namespace cnf {
 
 constexpr int PWL_H = 16;                 // hidden width this path is built for
 constexpr int PWL_P = 16;                 // spline parameters (K = 5)
-constexpr int PWL_NBP = 320;              // sorted breakpoints, +inf padded (>= 289 + sentinel)
+constexpr int PWL_NBP = 320;              // sorted breakpoints, NaN padded (>= 289 + sentinel)
 constexpr int PWL_NG = 2048;              // search grid cells over [PWL_GMIN, -PWL_GMIN), one uint16 each
 constexpr int PWL_NPIECE = 289;
 constexpr float PWL_GMIN = -16.0f;
@@ -168,7 +168,8 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
   __syncthreads();
   float* T = tables + (int64_t)blockIdx.x * PWL_TBL;
   for (int p = tid; p < PWL_NBP; p += blockDim.x)
-    T[p] = p == PWL_N_SLOT ? __int_as_float(n) : (p < n ? (float)cand[p] : __int_as_float(0x7f800000));
+    // padding: NaN -- `bp <= u` is false for every u, +inf included, so the searches stop there unaided
+    T[p] = p == PWL_N_SLOT ? __int_as_float(n) : (p < n ? (float)cand[p] : __int_as_float(0x7fc00000));
   // affine map of every piece, PWL_CHUNK pieces per pass:
   //   stage 1, task (p, k): second-layer pre-activation P u + Q on the piece (zeroed if its ReLU is off)
   //   stage 2, task (p, m): theta_m = S u + T
@@ -260,19 +261,43 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
   // against two breakpoints unconditionally and loop only in such cells (cell 0 / the last cell also serve every
   // u beyond the grid).  PWL_G_GENERAL: the cell touches a piece that needs the general spline evaluation, or is
   // one of the two outermost cells.
-  for (int g = tid; g < PWL_NG; g += blockDim.x) {
-    const double x = (double)PWL_GMIN + (double)g / (double)PWL_GSCALE - 1e-4;
-    int lo_ = 0, hi_ = g == 0 ? 0 : n;          // cell 0 also serves every u below the grid: search from piece 0
-    while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (cand[mid] <= x) lo_ = mid + 1; else hi_ = mid; }
-    const double xr = g == PWL_NG - 1 ? INF : (double)PWL_GMIN + (double)(g + 1) / (double)PWL_GSCALE + 1e-4;
-    int mark = (g == 0 || g == PWL_NG - 1) ? 1 : 0;
-    for (int p = lo_; p <= n && !mark; ++p) {          // pieces lo_ .. the one holding the cell's right edge
-      mark |= bad[p];
-      if (p < n && cand[p] > xr) break;
+  // Four cells per thread, their binary searches interleaved (a fixed 9 halvings cover n <= 289): the step is
+  // a chain of dependent LDS reads, and four independent chains cost what one does.
+  constexpr int CPT = 4;
+  static_assert(PWL_NG % CPT == 0 && PWL_NPIECE <= 512, "grid step: 9 halvings");
+  for (int g0 = tid; g0 < PWL_NG / CPT; g0 += blockDim.x) {
+    int lo_[CPT], hi_[CPT];
+    double x[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int g = g0 + i * (PWL_NG / CPT);
+      x[i] = (double)PWL_GMIN + (double)g / (double)PWL_GSCALE - 1e-4;
+      lo_[i] = 0;
+      hi_[i] = g == 0 ? 0 : n;                  // cell 0 also serves every u below the grid: search from piece 0
     }
-    const bool many = lo_ + 2 < n && cand[lo_ + 2] <= xr;      // a third breakpoint a sample of the cell can pass
-    reinterpret_cast<uint16_t*>(T + PWL_OFF_GRID)[g] =
-        (uint16_t)((uint32_t)lo_ | (mark ? PWL_G_GENERAL : 0u) | (many ? PWL_G_MANY : 0u));
+    for (int step = 0; step < 9; ++step) {
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const int mid = (lo_[i] + hi_[i]) >> 1;
+        const bool open = lo_[i] < hi_[i];
+        const bool le = cand[open ? mid : 0] <= x[i];
+        lo_[i] = open && le ? mid + 1 : lo_[i];
+        hi_[i] = open && !le ? mid : hi_[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int g = g0 + i * (PWL_NG / CPT);
+      const double xr = g == PWL_NG - 1 ? INF : (double)PWL_GMIN + (double)(g + 1) / (double)PWL_GSCALE + 1e-4;
+      int mark = (g == 0 || g == PWL_NG - 1) ? 1 : 0;
+      for (int p = lo_[i]; p <= n && !mark; ++p) {          // pieces lo_ .. the one holding the cell's right edge
+        mark |= bad[p];
+        if (p < n && cand[p] > xr) break;
+      }
+      const bool many = lo_[i] + 2 < n && cand[lo_[i] + 2] <= xr;      // a third breakpoint a sample of the cell can pass
+      reinterpret_cast<uint16_t*>(T + PWL_OFF_GRID)[g] =
+          (uint16_t)((uint32_t)lo_[i] | (mark ? PWL_G_GENERAL : 0u) | (many ? PWL_G_MANY : 0u));
+    }
   }
 }
 
@@ -324,10 +349,10 @@ __device__ __forceinline__ int pwl_piece(const float* tbl, float u, bool& genera
   const uint32_t g = reinterpret_cast<const uint16_t*>(tbl + PWL_OFF_GRID)[pwl_cell(u)];
   general = (g & PWL_G_GENERAL) != 0;
   int p = (int)(g & PWL_G_INDEX);
-  const float us = fminf(u, 3.0e38f);            // u = +inf must stop at the +inf padding too
+  const float us = u;                            // (the padding is NaN: no comparison with it succeeds)
   const float b0 = tbl[p], b1 = tbl[p + 1];      // sorted: b1 <= us implies b0 <= us
   p += (b0 <= us ? 1 : 0) + (b1 <= us ? 1 : 0);
-  if (g & PWL_G_MANY) while (tbl[p] <= us) ++p;  // bp[>= n] = +inf: terminates
+  if (g & PWL_G_MANY) while (tbl[p] <= us) ++p;  // bp[>= n] = NaN: terminates
   return p;
 }
 // Two samples: one wave-level branch for the rare loop.
@@ -336,7 +361,7 @@ __device__ __forceinline__ void pwl_piece(const float* tbl, v2f u, int& px, int&
   const uint32_t gx = grid[pwl_cell(u.x)], gy = grid[pwl_cell(u.y)];
   general = ((gx | gy) & PWL_G_GENERAL) != 0;
   px = (int)(gx & PWL_G_INDEX); py = (int)(gy & PWL_G_INDEX);
-  const float ux = fminf(u.x, 3.0e38f), uy = fminf(u.y, 3.0e38f);
+  const float ux = u.x, uy = u.y;
   const float ax0 = tbl[px], ax1 = tbl[px + 1], ay0 = tbl[py], ay1 = tbl[py + 1];
   px += (ax0 <= ux ? 1 : 0) + (ax1 <= ux ? 1 : 0);
   py += (ay0 <= uy ? 1 : 0) + (ay1 <= uy ? 1 : 0);
