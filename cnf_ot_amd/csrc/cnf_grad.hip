@@ -58,6 +58,14 @@ struct GradArgs {
   uint32_t div_magic;
 };
 
+// A wave zeroes its own gradient slab before its first tile (the host used to clear all slabs with one memset
+// per term: a 10 MB fill kernel and its launch in front of every backward launch).  Same wave, same addresses
+// later: the read-modify-writes that follow are ordered behind these stores.
+__device__ __forceinline__ void slab_clear(float* gslab, int64_t n_params, int lane) {
+  for (int64_t j = lane; j < n_params; j += 64) gslab[j] = 0.0f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+
 struct FirstAcc { float Wb[GK], Hb[GK], Db[GK + 1]; };
 
 __device__ __forceinline__ void tile_load1(const float* __restrict__ g, float* U, int D, uint32_t magic,
@@ -255,6 +263,7 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void grad_kernel(const
   const int tid = threadIdx.x;
   const int kind = a.spec.kind;
   float* gslab = a.slabs + ((int64_t)blockIdx.x * (GTS >> 6) + (tid >> 6)) * a.n_params;
+  slab_clear(gslab, a.n_params, tid & 63);
   FirstAcc fa;
 #pragma unroll
   for (int j = 0; j < GK; ++j) { fa.Wb[j] = 0.0f; fa.Hb[j] = 0.0f; }
@@ -479,6 +488,7 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void vjp_kernel(const 
   float* Ab = Aa + DT;
   float* stage = Ab + DT + (threadIdx.x >> 6) * STAGE_FLOATS;       // (WGRAD = false: only the h1 region is touched)
   float* gslab = WGRAD ? a.slabs + ((int64_t)blockIdx.x * (GTS >> 6) + (threadIdx.x >> 6)) * a.n_params : nullptr;
+  if (WGRAD) slab_clear(gslab, a.n_params, threadIdx.x & 63);
   for (int i = threadIdx.x; i < HDR; i += GTS) tab[i] = a.m.prep[i];
   const int tid = threadIdx.x;
   FirstAcc fa;      // WGRAD=false: written, never read: removed by the compiler
@@ -809,7 +819,6 @@ extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const f
   const size_t lds = grad_lds_bytes(D, L, ts);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
   const int64_t n_slabs = grid * (ts / 64);
-  if (hipMemsetAsync(m->grad_slabs, 0, sizeof(float) * (size_t)(n_slabs * m->n_params), stream) != hipSuccess) return CNF_ERR_HIP;
   if (m->fast_math) {
     if (!ensure_lds(grad_kernel<true>, lds)) return CNF_ERR_HIP;
     hipLaunchKernelGGL(grad_kernel<true>, dim3((unsigned)grid), dim3(ts), lds, stream, a);
@@ -878,7 +887,6 @@ static int pass_vjp_impl(CnfModel* m, int to_base, const float* pts, const float
   }
   if (grid > m->grad_max_blocks * 4 / (ts / 64)) grid = m->grad_max_blocks * 4 / (ts / 64);
   const int64_t n_slabs = grid * (ts / 64);
-  if (hipMemsetAsync(m->grad_slabs, 0, sizeof(float) * (size_t)(n_slabs * m->n_params), stream) != hipSuccess) return CNF_ERR_HIP;
   if (m->fast_math) {
     if (!ensure_lds(vjp_kernel<true, true>, lds)) return CNF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((vjp_kernel<true, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
@@ -931,7 +939,6 @@ extern "C" int cnf_logprob_fd_vjp(CnfModel* m, const float* pts, const float* c,
   int64_t grid = (a.B + tp - 1) / tp;
   if (grid > m->grad_max_blocks * 4 / (ts / 64)) grid = m->grad_max_blocks * 4 / (ts / 64);
   const int64_t n_slabs = grid * (ts / 64);
-  if (hipMemsetAsync(m->grad_slabs, 0, sizeof(float) * (size_t)(n_slabs * m->n_params), stream) != hipSuccess) return CNF_ERR_HIP;
   if (m->fast_math) {
     if (!ensure_lds(vjp_kernel<true, true>, lds)) return CNF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((vjp_kernel<true, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
