@@ -178,10 +178,13 @@ def _score_terms_unfused(ctx, conds, batch_size, dt, dx, coef_score, loss_coef, 
   z, _, count = ctx.noise(batch_size)
   S = len(conds)
   n = S * count
-  t = torch.as_tensor(np.asarray(conds, dtype=np.float32), device=z.device)
-  tt = t.repeat_interleave(count)                             # per-sample condition
+  # conditions per SLICE (the engine broadcasts a slice's value over its `count` samples): 3 S floats, built on the
+  # host and uploaded once per distinct time batch -- not per-sample tensors assembled by a chain of small kernels
+  th = np.asarray(conds, dtype=np.float32).reshape(-1)
+  half = np.float32(0.5 * dt)
+  tt = be.slice_conds(th)
+  c3 = be.slice_conds(np.concatenate([th - half, th + half, th]))
   z3 = z.repeat(3 * S, 1)                                     # the same draw for every slice and condition
-  c3 = torch.cat([tt - 0.5 * dt, tt + 0.5 * dt, tt])
   want = ctx.grad is not None
   r, _ = be.forward_logdet(z3, c3, want_logdet=False)
   r3 = r[2 * n:]
@@ -199,7 +202,7 @@ def _reverse_kl_unfused(ctx, T, beta, cond, batch_size, coef):
   dimensions where a rank's share of the batch cannot fill the GPU from inside the fused kernel."""
   be = ctx.be
   z, _, count = ctx.noise(batch_size)
-  c = torch.tensor([cond], dtype=torch.float32, device=z.device)
+  c = be.slice_conds([cond])
   y, lp = be.sample_logprob(z, c)
   want = ctx.grad is not None
   total, ybar, lpbar = be.rkl_residual(y, lp, cond, T, beta, coef, want)

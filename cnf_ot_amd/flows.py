@@ -270,7 +270,7 @@ class FlowEngine:
     return self._run(self.lib.cnf_sample_logprob, "cnf_sample_logprob", noise, cond, True, want_logp,
                      out=out, aux=logp_out)
 
-  def _slice_conds(self, t) -> torch.Tensor:
+  def slice_conds(self, t) -> torch.Tensor:
     """[n_slices] float32 on the device.  Host lists are uploaded once and kept (a loss evaluation asks for the
     same few condition lists -- [0], [T], the step's time batch -- for every term, loss and gradient alike)."""
     if torch.is_tensor(t):
@@ -290,7 +290,7 @@ class FlowEngine:
     loss term.  pts: base noise (or data points) [B, D] if `shared` else
     [n_slices*B, D]; t: [n_slices]."""
     pts = self._points(pts, "loss_terms")
-    t = self._slice_conds(t)
+    t = self.slice_conds(t)
     n_slices = t.numel()
     need = B if shared else n_slices * B
     if pts.shape[0] != need:
@@ -309,7 +309,7 @@ class FlowEngine:
     """cnf_loss_terms_seeded: as `loss_terms`, base noise drawn in the kernel
     (sample i of slice s = stream sample first_sample + s*slice_stride + i)."""
     seed, off = seed_to_u64(seed)
-    t = self._slice_conds(t)
+    t = self.slice_conds(t)
     sums = torch.empty(t.numel(), dtype=torch.float64, device=self.device)
     if self._pwl_mode and t.numel() > 0:
       self.reserve(t.numel(), _sets_of(spec))
@@ -330,7 +330,7 @@ class FlowEngine:
         _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
       self._grad_enabled = True
     pts = self._points(pts, "loss_terms_grad")
-    t = self._slice_conds(t)
+    t = self.slice_conds(t)
     n_slices = t.numel()
     need = B if shared else n_slices * B
     if pts.shape[0] != need:
