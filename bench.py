@@ -49,13 +49,13 @@ BATCH = 65536
 FLOP_PER_SAMPLE = 2176 + 400          # conditioner MLP + splines (the reference's formulation)
 FLOP_PER_SAMPLE_D10 = 21888 + 2400
 # what the dim-2 table path executes: the conditioner is read from exact piecewise-linear tables,
-# 16 FMAs per layer instead of the 544-FMA MLP
-EXECUTED_FLOP_PER_SAMPLE = 2 * 32 + 400
+# 12 FMAs per layer (10 softmax logits + the selected bin's 2 slope logits) instead of the 544-FMA MLP
+EXECUTED_FLOP_PER_SAMPLE = 2 * 24 + 400
 BYTES_PER_SAMPLE = 4 * (2 * DIM + 1)  # x in, y out, log_prob out (c is per slice)
 PEAK_FP32_TFLOPS = 157.3              # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 PEAK_HBM_GBS = 8000.0
 KERNEL_NAMES = {
-  "tables": "cnf::flow_pwl_kernel<5,false,true> (conditioner from piecewise-linear tables built by "
+  "tables": "cnf::flow_pwl_kernel<5,false,true,false,289,2> (conditioner from piecewise-linear tables built by "
             "cnf::pwl_build_kernel; packed fp32 VALU flow, 2 samples/lane)",
   "mlp2": "cnf::flow_kernel<16,5,false,true,v2f> (conditioner MLP in packed fp32 VALU, 2 samples/lane)",
   "mlp1": "cnf::flow_kernel<16,5,false,true,float> (conditioner MLP, 1 sample/lane)",
@@ -410,7 +410,7 @@ def main():
                                     "frac": achieved_tflops / PEAK_FP32_TFLOPS},
       "note": "SURVEY.md 8(d) derived an fp32-ALU bound of 60 G samples/s from the reference formulation (2576 flop "
               "per sample: 2-16-16-16 MLP conditioner + splines).  The table path reads the same conditioner from "
-              "exact piecewise-linear tables and executes ~464 flop per sample, so that figure is no longer a bound "
+              "exact piecewise-linear tables and executes ~448 flop per sample, so that figure is no longer a bound "
               "(alu_reference_formulation.frac can exceed 1); the bound left is HBM.  What limits the kernel is "
               "VALU issue (DESIGN.md 5.1d).",
     },
