@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void loss_pwl_kernel(const LossPwl
     T y0 = n0, y1 = n1, va = splat<T>(0.0f), vb = splat<T>(0.0f);     // (va, vb): r1, then the velocity
     for (int p = 0; p < n_fwd; ++p) {                                  // set p: conditions t - dt/2, t + dt/2, t (kin) or t
       y0 = n0; y1 = n1;
-      fldj = flow2_tables<K, false, FAST>(tab, tbl + p * L * PWL_LTBL, gslice + p * set_stride, L, sc, y0, y1);
+      fldj = flow2_tables<K, false, FAST, false, true>(tab, tbl + p * L * PWL_LTBL, gslice + p * set_stride, L, sc, y0, y1);
       if (kin) {
         if (p == 0) { va = y0; vb = y1; }
         else if (p == 1) { const float inv_dt = 1.0f / dt; va = (y0 - va) * inv_dt; vb = (y1 - vb) * inv_dt; }
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void loss_pwl_kernel(const LossPwl
         const float h = sgn == 0 ? 0.5f * dx : -0.5f * dx;
         if (d == 0) u0 = u0 + h; else u1 = u1 + h;
       }
-      const T ildj = flow2_tables<K, true, FAST>(tab, tbl + tset * L * PWL_LTBL, gslice + tset * set_stride, L, sc, u0, u1);
+      const T ildj = flow2_tables<K, true, FAST, false, true>(tab, tbl + tset * L * PWL_LTBL, gslice + tset * set_stride, L, sc, u0, u1);
       const T lp = vfma(u0 * -0.5f, u0, u1 * u1 * -0.5f) - (float)(2 * HALF_LOG_2PI) + ildj;
       if (neg) acc = -lp;
       else if (sgn == 0) lp0 = lp;
