@@ -1121,7 +1121,7 @@ __host__ __device__ inline void threefry2x32_20(uint32_t k0, uint32_t k1, uint32
   o0 = x0; o1 = x1;
 }
 
-__global__ void fill_normal_threefry_kernel(uint32_t k0, uint32_t k1, uint64_t size, uint64_t first, int64_t n,
+__global__ __launch_bounds__(256) void fill_normal_threefry_kernel(uint32_t k0, uint32_t k1, uint64_t size, uint64_t first, int64_t n,
                                             float* __restrict__ out32, double* __restrict__ out64) {
   const double lo = -0.99999999999999988897769753748;        // nextafter(-1, 0)
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

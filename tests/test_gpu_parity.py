@@ -151,13 +151,13 @@ def test_config2_batch_65536_vs_oracle(dev, params_kind, t, spl, mfma):
   assert elpd.max() <= TOL_LP_FP32_MAX and np.quantile(elpd, 0.999) <= TOL_LP_FP32_P999
 
 
-def _zigzag_params(rng, n):
+def _zigzag_params(rng, n, L=2):
   """Conditioners whose second-layer units are triangle waves of u crossing
   zero in every first-layer interval: ~256 linear pieces per table (the bound
-  is 289), far past the 128 rows the flow kernel keeps in LDS."""
+  is 289), far past the 112 rows the windowed kernels keep in LDS."""
   params = np.zeros(n)
   params[:16] = rng.normal(0, 0.3, 16)
-  for l in range(2):
+  for l in range(L):
     w = params[16 + 592 * l: 16 + 592 * (l + 1)]
     w[16:32] = 1.0                                  # W0[u row]; the c row stays 0
     w[32:48] = -np.linspace(-7.5, 7.5, 16)          # b0: breakpoints at -7.5 .. 7.5
@@ -276,6 +276,39 @@ def test_table_path_other_depths(dev, L):
   eng.set_pwl(0)
   y0, lp0 = eng.sample_logprob(_t(noise, dev), _t(ts, dev))
   assert (y0 - y).abs().max().item() <= 2e-5 and (lp0 - lp).abs().max().item() <= 2e-5
+
+
+def test_table_rows_past_the_lds_window(dev):
+  """With L <= 3 the flow kernel stages every row of its tables; with L = 4 it keeps the first 112 rows of each
+  in LDS and reads the rest from the global table -- `zigzag` tables have ~256.  Both row paths must give the
+  same function: the L = 4 table result is compared with the MLP kernel and with the fp32 port of the oracle
+  (the set is ill-conditioned: see test_config2_piecewise_linear_tables)."""
+  import oracle
+  L = 4
+  fcfg, ocfg = _cfg_pair(D=2, L=L)
+  rng = np.random.default_rng(77)
+  params = _zigzag_params(rng, oracle.param_count(ocfg), L)
+  S, Bs = 3, 6000
+  noise = rng.normal(size=(S * Bs, 2)).astype(np.float32)
+  ts = np.array([0.2, 0.5, 0.8])
+  c_host = np.repeat(ts, Bs)
+  eng = _engine(fcfg, params, dev)
+  eng.set_pwl(2)
+  y, lp = eng.sample_logprob(_t(noise, dev), _t(ts, dev))
+  assert eng.last_path() == "tables"
+  y_ref, lp_ref = oracle.sample_logprob(ocfg, params, noise.astype(np.float64), c_host)
+  y32, lp32 = oracle.sample_logprob(ocfg, params.astype(np.float32), noise, c_host.astype(np.float32), dtype=np.float32)
+  ey, elp = _err(y, y_ref), _err(lp, lp_ref)
+  print(f"\n[rows past the window, L=4 zigzag] tables max|dy|={ey.max():.2e} max|dlogp|={elp.max():.2e}; "
+        f"fp32 port {np.abs(y32 - y_ref).max():.2e} / {np.abs(lp32 - lp_ref).max():.2e}")
+  assert ey.max() <= 2 * np.abs(y32 - y_ref).max() + TOL_Y and elp.max() <= 2 * np.abs(lp32 - lp_ref).max() + TOL_LP_SAMPLE
+  assert np.median(elp) <= 2 * np.median(np.abs(lp32 - lp_ref)) + 1e-6
+  # data -> base through the same rows (precise positions), round trip to the noise
+  xb, _ = eng.inverse_logdet(y, _t(ts, dev))
+  assert eng.last_path() == "tables"
+  rt = (xb - _t(noise, dev)).abs()
+  print(f"[rows past the window] round trip median {rt.median().item():.2e} max {rt.max().item():.2e}")
+  assert rt.median().item() <= 5e-5      # (measured 1.1e-5: four ill-conditioned layers in fp32)
 
 
 def test_table_path_randomised_against_mlp_kernel_and_oracle(dev):
