@@ -502,7 +502,7 @@ __global__ __launch_bounds__(1024) void flow_dpar_kernel(const FlowArgs a) {
 // flow_pwl_kernel: the dim-2 flow with the conditioner read from the exact
 // piecewise-linear tables of cnf_pwl.h (condition uniform per slice).  One
 // 1024-thread workgroup per CU keeps the L tables of its current slice in LDS
-// (L x 21 KB: header arrays + the first PWL_LROWS rows); each lane owns
+// (every row when L <= 3: L x 48 KB; else L x 22 KB: header arrays + the first PWL_LROWS rows); each lane owns
 // two consecutive samples, whose 4 input floats are one 16-byte load and whose
 // outputs are one 16-byte + one 8-byte store -- no LDS staging of the points.
 // ---------------------------------------------------------------------------
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(TILE, 2) void loss_kernel(const LossArgs a) {
 // loss_pwl_kernel: the fused loss terms at dim 2 on the conditioner tables.
 // Same terms and arithmetic as loss_kernel; a sample pair lives in registers,
 // the passes of a term use up to three table sets (conditions t - dt/2,
-// t + dt/2, t), each L x 21 KB in LDS.  Base noise comes from `pts` or from the
+// t + dt/2, t), each L x 22 KB in LDS.  Base noise comes from `pts` or from the
 // Philox stream (one counter block = the pair's four normals when aligned).
 // ---------------------------------------------------------------------------
 struct LossPwlArgs {
@@ -1612,7 +1612,7 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
                 : (l2 ? (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, ALL, 2>
                       : full ? (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, ALL> : (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, WIN>);
   if (!ensure_lds(kern, lds)) return CNF_ERR_UNSUPPORTED;
-  // at most PWL_MAX_SLICES slices per kernel pair: the workspace stays bounded (2 048 x L x 46 KB) however many
+  // at most PWL_MAX_SLICES slices per kernel pair: the workspace stays bounded (2 048 x L x 48 KB) however many
   // slices a call has
   int64_t chunk = n_slices < PWL_MAX_SLICES ? n_slices : PWL_MAX_SLICES;
   float* tables = nullptr;

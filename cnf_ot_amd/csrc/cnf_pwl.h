@@ -47,7 +47,7 @@ constexpr int PWL_ROW = 36;
 constexpr int PWL_TBL = PWL_OFF_PIECE + PWL_NPIECE * PWL_ROW;          // floats per (slice, layer): 11 540
 // The flow and loss kernels stage the header arrays and the first PWL_LROWS rows in LDS (networks met in
 // practice have 30-50 pieces; 289 is the worst case); rows beyond that are read from the global table.
-// 23 KB per table instead of 46 KB: the loss kernel keeps up to three table sets of L = 2 layers in LDS.
+// 22 KB per table instead of 48 KB: the loss kernel keeps up to three table sets of L = 2 layers in LDS.
 constexpr int PWL_LROWS = 112;
 constexpr int PWL_LTBL = PWL_OFF_PIECE + PWL_LROWS * PWL_ROW;
 // The flow kernel (one table set, L <= 3 layers) stages EVERY row instead (L x 46 KB of its 160 KB): no piece is
