@@ -25,6 +25,7 @@ class CnfConfig(ctypes.Structure):
     ("num_bins", ctypes.c_int32),
     ("range_min", ctypes.c_float), ("range_max", ctypes.c_float),
     ("min_bin_size", ctypes.c_float), ("min_knot_slope", ctypes.c_float),
+    ("periodized", ctypes.c_int32),
   ]
 
 

@@ -919,26 +919,59 @@ __device__ __forceinline__ void lds_put(float* col, int idx, int stride, v2f v) 
   *reinterpret_cast<v2f*>(col + idx * stride) = v;
 }
 
-template <int H, int P, class T>
+// sin / cos of a conditioner input for the periodized model (flows.py:58-64): ocml's full-accuracy functions in
+// every math mode -- two per input next to a 2 (1 + d) x H matrix product
+__device__ __forceinline__ void vsincos(float x, float& s, float& c) { s = sinf(x); c = cosf(x); }
+__device__ __forceinline__ void vsincos(double x, double& s, double& c) { s = ::sin(x); c = ::cos(x); }
+__device__ __forceinline__ void vsincos(v2f x, v2f& s, v2f& c) {
+  s = v2f{sinf(x.x), sinf(x.y)}; c = v2f{cosf(x.x), cosf(x.y)};
+}
+
+// PERIODIC: the first linear layer has 2 (1 + d) rows and sees [sin(c), sin(v_0) .., cos(c), cos(v_0) ..]
+// (jnp.concatenate([sin(x)], [cos(x)]) of x = [c, v], flows.py:58-64 with num_fourier_feat = 1).
+template <int H, int P, class T, bool PERIODIC = false>
 __device__ __forceinline__ void conditioner(uniform_ptr w, int d, int M, T c, const typename Lanes<T>::real* col,
                                             int first_idx, int idx_step, int stride, T (&th)[P]) {
   T h[H];
   w = launder(w);
-  uniform_ptr b0 = w + (1 + d) * H;
-  {
-    float wc[H], bb[H];
-    load_row<H>(w, wc);
-    load_row<H>(b0, bb);
+  uniform_ptr b0 = w + (PERIODIC ? 2 : 1) * (1 + d) * H;
+  if constexpr (PERIODIC) {
+    T sn, cs;
+    vsincos(c, sn, cs);
+    {
+      float ws[H], wc[H], bb[H];
+      load_row<H>(w, ws);
+      load_row<H>(w + (1 + d) * H, wc);
+      load_row<H>(b0, bb);
 #pragma unroll
-    for (int j = 0; j < H; ++j) h[j] = vfma(wc[j], c, splat<T>(bb[j]));
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  for (int q = 0; q < d; ++q) {              // runtime loop: d is not a template arg
-    const T v = lds_get<T>(col, first_idx + q * idx_step, stride);
-    float wr[H];
-    load_row<H>(w + (1 + q) * H, wr);
+      for (int j = 0; j < H; ++j) h[j] = vfma(wc[j], cs, vfma(ws[j], sn, splat<T>(bb[j])));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int q = 0; q < d; ++q) {
+      const T v = lds_get<T>(col, first_idx + q * idx_step, stride);
+      vsincos(v, sn, cs);
+      float ws[H], wc[H];
+      load_row<H>(w + (1 + q) * H, ws);
+      load_row<H>(w + (2 + d + q) * H, wc);
 #pragma unroll
-    for (int j = 0; j < H; ++j) h[j] = vfma(wr[j], v, h[j]);
+      for (int j = 0; j < H; ++j) h[j] = vfma(wc[j], cs, vfma(ws[j], sn, h[j]));
+    }
+  } else {
+    {
+      float wc[H], bb[H];
+      load_row<H>(w, wc);
+      load_row<H>(b0, bb);
+#pragma unroll
+      for (int j = 0; j < H; ++j) h[j] = vfma(wc[j], c, splat<T>(bb[j]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int q = 0; q < d; ++q) {              // runtime loop: d is not a template arg
+      const T v = lds_get<T>(col, first_idx + q * idx_step, stride);
+      float wr[H];
+      load_row<H>(w + (1 + q) * H, wr);
+#pragma unroll
+      for (int j = 0; j < H; ++j) h[j] = vfma(wr[j], v, h[j]);
+    }
   }
 #pragma unroll
   for (int j = 0; j < H; ++j) h[j] = vrelu(h[j]);
@@ -1153,8 +1186,14 @@ __device__ __forceinline__ void conditioner_mfma(const f4* __restrict__ wq, int 
 // floats of one conditioner's MFMA-layout block: (1+d) W0 rows, b0, M x {A, bias}, 64 lanes x 4
 __host__ __device__ inline int64_t cond_floats_mfma(int d, int M) { return 256 * (int64_t)((1 + d) + 1 + 2 * M); }
 
-__host__ __device__ inline int64_t cond_floats(int d, int H, int M, int P) {
-  return (int64_t)(1 + d) * H + H + (int64_t)(M - 1) * (H * H + H) + (int64_t)H * P + P;
+// floats of one conditioner whose first linear layer has `rows` inputs
+__host__ __device__ inline int64_t cond_floats_rows(int rows, int H, int M, int P) {
+  return (int64_t)rows * H + H + (int64_t)(M - 1) * (H * H + H) + (int64_t)H * P + P;
+}
+__host__ __device__ inline int64_t cond_floats(int d, int H, int M, int P) { return cond_floats_rows(1 + d, H, M, P); }
+// periodized (flows.py:58-64): the MLP sees [sin(c, v), cos(c, v)]: 2 (1 + d) rows
+__host__ __device__ inline int64_t cond_floats_p(int d, int H, int M, int P, bool periodic) {
+  return cond_floats_rows((periodic ? 2 : 1) * (1 + d), H, M, P);
 }
 
 // ---------------------------------------------------------------------------

@@ -58,6 +58,22 @@ template <class A> __device__ __forceinline__ bool gate_closed(const A& a) {
   return a.gate && ((*a.gate == a.gate_epoch) ? 1 : 0) != a.gate_want;
 }
 
+// boundary_slopes='circular' (RQSFlow(periodized=True), flows.py:131): the last knot's unnormalized slope IS the
+// first knot's.  Run after prepare_kernel on the same stream: in the weight snapshot, column 3K of every output
+// layer becomes a copy of column 2K, so the kernels produce theta[3K] == theta[2K] bit for bit with no code of
+// their own (the caller's parameters are not touched).  One block per conditioner.
+__global__ void circular_slopes_kernel(const float* __restrict__ params, float* __restrict__ prep, int K, int H,
+                                       int D, int L, int M, int64_t per_layer) {
+  const int P = 3 * K + 1;
+  const int hdr = hdr_floats(K);
+  const int l = blockIdx.x / (D - 1), d = 1 + blockIdx.x % (D - 1);
+  int64_t o = (int64_t)l * per_layer;
+  for (int dd = 1; dd < d; ++dd) o += cond_floats_p(dd, H, M, P, true);
+  o += cond_floats_p(d, H, M, P, true) - ((int64_t)H * P + P);       // this conditioner's output layer
+  for (int r = threadIdx.x; r <= H; r += blockDim.x)                  // H weight rows + the bias row
+    prep[hdr + o + (int64_t)r * P + 3 * K] = params[P + o + (int64_t)r * P + 2 * K];
+}
+
 // ---------------------------------------------------------------------------
 // prepare_kernel: params (flat, caller-owned) -> prepared model buffer.
 // Thread 0 normalises the `first` spline in float64; all threads snapshot the
@@ -66,7 +82,7 @@ template <class A> __device__ __forceinline__ bool gate_closed(const A& a) {
 __global__ void prepare_kernel(const float* __restrict__ params, float* __restrict__ prep,
                                int K, int64_t n_params, double lo, double hi, double min_bin,
                                double min_slope, int D, int L, int M, int64_t per_layer,
-                               int64_t per_layer_q, int64_t mfma_off, int64_t tabd_off) {
+                               int64_t per_layer_q, int64_t mfma_off, int64_t tabd_off, int H, int periodic) {
   const int P = 3 * K + 1;
   const int hdr = hdr_floats(K);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_params - P;
@@ -121,7 +137,7 @@ __global__ void prepare_kernel(const float* __restrict__ params, float* __restri
   }
   const double offset = log(exp(1.0 - min_slope) - 1.0);
   for (int k = 0; k <= K; ++k) {
-    const double v = (double)params[2 * K + k] + offset;
+    const double v = (double)params[2 * K + (periodic && k == K ? 0 : k)] + offset;      // circular: slope K := slope 0
     dl[k] = fmax(v, 0.0) + log1p(exp(-fabs(v))) + min_slope;
   }
   double* td = reinterpret_cast<double*>(prep + tabd_off);     // the same table in float64
@@ -259,7 +275,7 @@ __device__ __forceinline__ v2f hsum(v2f v) { return v; }
 // Returns the accumulated log|det J|; the result is left in `U` (swapped).
 // PRECISE (TO_BASE only): the precise position path of cnf_device.h; `e2tab` is its 2^(-i/32) table in LDS and
 // `bacc` receives sum_d x_d^2 of the recovered base point in float64.
-template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false, bool PRECISE = false>
+template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false, bool PRECISE = false, bool PERIODIC = false>
 __device__ __forceinline__ T flow_pass(const ModelArgs& a, const typename Lanes<T>::real* tab,
                                        typename Lanes<T>::real*& U, typename Lanes<T>::real*& O, T c,
                                        const double* e2tab = nullptr, const double* tabd = nullptr,
@@ -268,6 +284,7 @@ __device__ __forceinline__ T flow_pass(const ModelArgs& a, const typename Lanes<
   static_assert(!PRECISE || (TO_BASE && !std::is_same<T, double>::value), "precise path: data -> base, fp32 kernels");
   const SplineConstsT<R>& sc = sc_of<R>(a);
   static_assert(!MFMA || (H == 16 && K == 5), "the MFMA conditioner is built for H = 16, P = 16");
+  static_assert(!PERIODIC || (!MFMA && !PRECISE), "periodized: the scalar-weight conditioner, plain positions");
   constexpr int P = 3 * K + 1;
   constexpr bool INV = !TO_BASE;
   constexpr int SPL = Lanes<T>::N;
@@ -310,8 +327,8 @@ __device__ __forceinline__ T flow_pass(const ModelArgs& a, const typename Lanes<
         wq += cond_floats_mfma(d, a.M);
         w += cond_floats(d, H, a.M, P);
       } else {
-        conditioner<H, P, T>(w, d, a.M, c, TO_BASE ? co : cu, first_idx, idx_step, TS, th);
-        w += cond_floats(d, H, a.M, P);
+        conditioner<H, P, T, PERIODIC>(w, d, a.M, c, TO_BASE ? co : cu, first_idx, idx_step, TS, th);
+        w += cond_floats_p(d, H, a.M, P, PERIODIC);
       }
       if constexpr (PRECISE) {
         const T vlo = step == 0 ? splat<T>(0.0f) : lds_get<T>(clo, i, TS);
@@ -348,7 +365,7 @@ __device__ __forceinline__ void store_aux(float* aux, int64_t i, int64_t B, v2f 
   else { if (i < B) aux[i] = r.x; if (i + 1 < B) aux[i + 1] = r.y; }
 }
 
-template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false, bool PRECISE = false>
+template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false, bool PRECISE = false, bool PERIODIC = false>
 __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename Lanes<T>::real> a) {
   typedef typename Lanes<T>::real R;
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
@@ -385,7 +402,7 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
     T base = splat<T>(0.0f);
     if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = base_logprob<T>(U + SPL * threadIdx.x, a.m.D, TS);
     BaseAcc<T> bacc;
-    const T acc = flow_pass<H, K, TO_BASE, FAST, T, MFMA, PRECISE>(a.m, tab, U, O, c, e2tab, tabd, LO, &bacc);
+    const T acc = flow_pass<H, K, TO_BASE, FAST, T, MFMA, PRECISE, PERIODIC>(a.m, tab, U, O, c, e2tab, tabd, LO, &bacc);
     if (a.aux) {
       T r = acc;
       if (a.aux_mode == AUX_LOGPROB) {
@@ -1155,6 +1172,7 @@ static int config_valid(const CnfConfig* c) {
   if (!(c->range_min < c->range_max)) return 0;
   if (!(c->min_bin_size > 0.f) || !(c->min_knot_slope > 0.f) || !(c->min_knot_slope < 1.f)) return 0;
   if (c->num_bins * c->min_bin_size > c->range_max - c->range_min) return 0;   // distrax raises
+  if (c->periodized != 0 && c->periodized != 1) return 0;
   return 1;
 }
 
@@ -1170,6 +1188,7 @@ extern "C" void cnf_config_default(CnfConfig* c, int32_t dim) {
   if (!c) return;
   c->dim = dim; c->num_layers = 2; c->hidden_size = 16; c->mlp_num_layers = 2; c->num_bins = 5;
   c->range_min = -10.f; c->range_max = 10.f; c->min_bin_size = 1e-4f; c->min_knot_slope = 1e-4f;
+  c->periodized = 0;
 }
 
 extern "C" int64_t cnf_param_count(const CnfConfig* c) {
@@ -1177,7 +1196,7 @@ extern "C" int64_t cnf_param_count(const CnfConfig* c) {
   const int P = 3 * c->num_bins + 1;
   int64_t n = P;
   for (int d = 1; d < c->dim; ++d)
-    n += (int64_t)c->num_layers * cond_floats(d, c->hidden_size, c->mlp_num_layers, P);
+    n += (int64_t)c->num_layers * cond_floats_p(d, c->hidden_size, c->mlp_num_layers, P, c->periodized != 0);
   return n;
 }
 
@@ -1205,7 +1224,8 @@ extern "C" int cnf_model_create(const CnfConfig* cfg, CnfModel** out) {
   const int K = cfg->num_bins, P = 3 * K + 1;
   m->n_params = cnf_param_count(cfg);
   m->per_layer = 0;
-  for (int d = 1; d < cfg->dim; ++d) m->per_layer += cond_floats(d, cfg->hidden_size, cfg->mlp_num_layers, P);
+  for (int d = 1; d < cfg->dim; ++d)
+    m->per_layer += cond_floats_p(d, cfg->hidden_size, cfg->mlp_num_layers, P, cfg->periodized != 0);
   m->sc.lo = cfg->range_min; m->sc.hi = cfg->range_max;
   m->sc.min_bin = cfg->min_bin_size; m->sc.min_slope = cfg->min_knot_slope;
   m->sc.span_eff = (float)(((double)cfg->range_max - (double)cfg->range_min) - (double)K * (double)cfg->min_bin_size);
@@ -1227,7 +1247,7 @@ extern "C" int cnf_model_create(const CnfConfig* cfg, CnfModel** out) {
   m->div_magic = cfg->dim == 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + (uint64_t)cfg->dim - 1) / (uint64_t)cfg->dim);
   m->per_layer_q = 0; m->mfma_off = 0;
   size_t q_floats = 0;
-  if (cfg->hidden_size == 16 && P == 16 && cfg->dim > 1) {
+  if (cfg->hidden_size == 16 && P == 16 && cfg->dim > 1 && !cfg->periodized) {      // (no MFMA form of the sin / cos layer)
     for (int d = 1; d < cfg->dim; ++d) m->per_layer_q += cond_floats_mfma(d, cfg->mlp_num_layers);
     m->mfma_off = (hdr_floats(K) + (m->n_params - P) + 3) & ~(int64_t)3;
     q_floats = (size_t)m->per_layer_q * cfg->num_layers;
@@ -1385,7 +1405,11 @@ extern "C" int cnf_model_set_params(CnfModel* m, const float* params, void* stre
                      m->n_params, (double)m->cfg.range_min, (double)m->cfg.range_max,
                      (double)m->cfg.min_bin_size, (double)m->cfg.min_knot_slope, m->cfg.dim,
                      m->cfg.num_layers, m->cfg.mlp_num_layers, m->per_layer, m->per_layer_q, m->mfma_off,
-                     m->tabd_off);
+                     m->tabd_off, m->cfg.hidden_size, m->cfg.periodized);
+  if (m->cfg.periodized && m->cfg.dim > 1)
+    hipLaunchKernelGGL(circular_slopes_kernel, dim3((unsigned)(m->cfg.num_layers * (m->cfg.dim - 1))), dim3(64), 0,
+                       (hipStream_t)stream, params, m->prep, K, m->cfg.hidden_size, m->cfg.dim, m->cfg.num_layers,
+                       m->cfg.mlp_num_layers, m->per_layer);
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
   if (hipEventRecord(m->prep_event, (hipStream_t)stream) != hipSuccess) return CNF_ERR_HIP;
   m->prep_stream = stream;
@@ -1418,7 +1442,7 @@ static int samples_per_lane(const CnfModel* m, int64_t B) {
 // = 1) while the one-sample-per-lane kernel would leave the chip under-filled.
 static int launch_flow_dpar(CnfModel* m, const FlowArgs& a, hipStream_t stream) {
   const int D = m->cfg.dim;
-  if (D < 3 || !m->fast_math || m->use_mfma == 1 || !m->use_dpar) return CNF_ERR_UNSUPPORTED;
+  if (D < 3 || !m->fast_math || m->use_mfma == 1 || !m->use_dpar || m->cfg.periodized) return CNF_ERR_UNSUPPORTED;
   // measured crossover with the one-sample-per-lane kernel (MI355X, D = 3 and D = 10, scripts/exp_dim10.py):
   // between 131 072 and 524 288 samples; 512 samples per CU
   if (m->use_dpar == 1 && a.B > (int64_t)m->num_cus * 512) return CNF_ERR_UNSUPPORTED;
@@ -1456,6 +1480,23 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
   const int64_t cap = (int64_t)m->num_cus * 8;
   if (grid > cap) grid = cap;
   constexpr bool PR = TO_BASE;                 // the precise position path exists for the data -> base direction
+  if (m->cfg.periodized) {
+    // RQSFlow(periodized=True): one sample per lane, hardware transcendentals, plain fp32 positions; sin / cos of
+    // the conditioner inputs by ocml.  (fast_math off: the float64 entry points are the exact mode.)
+    if (!m->fast_math) return CNF_ERR_UNSUPPORTED;
+    const int64_t tiles1 = (a.B + TILE - 1) / TILE;
+    const int64_t grid1 = tiles1 < (int64_t)m->num_cus * 8 ? tiles1 : (int64_t)m->num_cus * 8;
+    const size_t lds1 = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * TILE) * sizeof(float);
+    if (!a.gate) m->last_path = CNF_PATH_MLP1;
+#define X(HH, KK)                                                                             \
+    if (m->cfg.hidden_size == HH && m->cfg.num_bins == KK) {                                  \
+      CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, true, float, false, false, true>), grid1, lds1, stream, a);  \
+      return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;                          \
+    }
+    CNF_KERNEL_CONFIGS(X)
+#undef X
+    return CNF_ERR_UNSUPPORTED;
+  }
   const bool precise = PR && m->precise;
   const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * ts) * sizeof(float) +
                      (precise ? precise_lds_bytes(m->cfg.num_bins) + sizeof(float) * a.m.D * ts : 0);
@@ -1550,7 +1591,7 @@ static const int64_t PWL_MAX_SLICES = 2048;      // slices per build + flow kern
 static bool pwl_config_ok(const CnfModel* m) {
   const CnfConfig& g = m->cfg;
   return m->use_pwl && m->fast_math && g.dim == 2 && g.hidden_size == cnf::PWL_H && g.num_bins == 5 &&
-         g.mlp_num_layers == 2;
+         g.mlp_num_layers == 2 && !g.periodized;      // (sin / cos features are not piecewise linear in u)
 }
 
 // The piecewise-linear path (cnf_pwl.h): dim 2, H = 16, K = 5, two MLP layers, a condition that is
@@ -1836,6 +1877,7 @@ static int loss_terms_impl(CnfModel* m, const CnfLossSpec* spec, const float* pt
   if (!m || !spec || !t || !sums || n_slices < 0 || B < 0 || slice_stride < 0 || first_sample < 0) return CNF_ERR_INVALID;
   if (!m->params_set) return CNF_ERR_INVALID;
   if (spec->kind < CNF_TERM_KINETIC || spec->kind > CNF_TERM_NEG_LOGPROB) return CNF_ERR_INVALID;
+  if (m->cfg.periodized) return CNF_ERR_UNSUPPORTED;      // flow functions only (include/cnf_ot_amd.h: CnfConfig)
   const int D = m->cfg.dim;
   if (spec->kind <= CNF_TERM_FLOW_MATCHING && !(spec->dt > 0.f)) return CNF_ERR_INVALID;
   if ((spec->kind == CNF_TERM_KINETIC_SCORE || spec->kind == CNF_TERM_FLOW_MATCHING) && !(spec->dx > 0.f))
@@ -1912,7 +1954,8 @@ static int launch_flow_f64(CnfModel* m, const FlowArgsD& a, hipStream_t stream) 
   const size_t lds = (size_t)(hdr_floats(m->cfg.num_bins) + 2 * a.m.D * TILE) * sizeof(double);
 #define X(HH, KK)                                                                    \
   if (m->cfg.hidden_size == HH && m->cfg.num_bins == KK) {                           \
-    CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, false, double>), grid, lds, stream, a); \
+    if (m->cfg.periodized) CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, false, double, false, false, true>), grid, lds, stream, a); \
+    else CNF_LAUNCH((flow_kernel<HH, KK, TO_BASE, false, double>), grid, lds, stream, a); \
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;                   \
   }
   CNF_KERNEL_CONFIGS(X)

@@ -783,7 +783,7 @@ template <class F> static int pick_tile(F lds_of) {
 extern "C" int cnf_grad_supported(const CnfConfig* c) {
   // hidden 16 / 2 hidden layers / 5 bins (the MFMA weight-gradient tiles are 16x16), dim <= 14 (the
   // first layer's inputs + bias row fit 16 MFMA rows), and the tile's LDS working set within one CU
-  return c && c->hidden_size == 16 && c->mlp_num_layers == 2 && c->num_bins == 5 && c->dim >= 1 && c->dim <= 14 &&
+  return c && !c->periodized && c->hidden_size == 16 && c->mlp_num_layers == 2 && c->num_bins == 5 && c->dim >= 1 && c->dim <= 14 &&
          c->num_layers >= 1 && grad_lds_bytes(c->dim, c->num_layers, 64) <= 160 * 1024;
 }
 

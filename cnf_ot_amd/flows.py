@@ -38,7 +38,7 @@ def mark_updated(flat: torch.Tensor) -> None:
 def _c_config(cfg: FlowConfig) -> _capi.CnfConfig:
   return _capi.CnfConfig(cfg.dim, cfg.num_layers, cfg.hidden_size, cfg.mlp_num_layers,
                          cfg.num_bins, cfg.range_min, cfg.range_max, cfg.min_bin_size,
-                         cfg.min_knot_slope)
+                         cfg.min_knot_slope, 1 if cfg.periodized else 0)
 
 
 def _stream_ptr(device) -> int:
@@ -655,10 +655,6 @@ def RQSFlow(
   """Same signature as cnf_ot/models/flows.py:178-186 (+ `rng`: "philox" = the
   build's own counter-based stream, "threefry" = `seed` is a JAX key and the
   base draw of sample / sample_and_log_prob is jax.random.normal's)."""
-  if periodized:
-    raise NotImplementedError(
-      "periodized=True (circular boundary slopes on [0, 2pi]) is not on the mfc hot "
-      "path: every reference call site passes periodized=False (solvers.py:46)")
   if len(tuple(event_shape)) != 1:
     raise ValueError("event_shape must be (dim,)")
   if tuple(cond_shape) != (1,):
@@ -666,7 +662,10 @@ def RQSFlow(
   hidden_sizes = list(hidden_sizes)
   if not hidden_sizes or any(h != hidden_sizes[0] for h in hidden_sizes):
     raise NotImplementedError("hidden_sizes must be [hidden_size] * mlp_num_layers (solvers.py:44)")
-  cfg = FlowConfig(dim=int(event_shape[0]), num_layers=int(num_layers),
-                   hidden_size=int(hidden_sizes[0]), mlp_num_layers=len(hidden_sizes),
-                   num_bins=int(num_bins))
+  # periodized (flows.py:58-64,127-131): sin / cos features, [0, 2 pi], circular slopes -- the flow functions
+  # (log_prob, sample, sample_and_log_prob, forward, inverse); losses and gradients are not built for it
+  make = FlowConfig.torus if periodized else FlowConfig
+  cfg = make(dim=int(event_shape[0]), num_layers=int(num_layers),
+             hidden_size=int(hidden_sizes[0]), mlp_num_layers=len(hidden_sizes),
+             num_bins=int(num_bins))
   return FlowModel(cfg, rng=rng)

@@ -32,6 +32,15 @@ class FlowConfig:
   range_max: float = 10.0
   min_bin_size: float = 1e-4
   min_knot_slope: float = 1e-4
+  # flows.py:58-64,127-131: the conditioner MLP sees [sin(x), cos(x)] of its input x = [c, v], the splines live on
+  # [0, 2 pi] (FlowConfig.torus sets the range) with boundary_slopes='circular'.  Flow functions only: the loss and
+  # gradient kernels do not take it (no reference call site does either).
+  periodized: bool = False
+
+  @staticmethod
+  def torus(**kw) -> "FlowConfig":
+    import math
+    return FlowConfig(range_min=0.0, range_max=2.0 * math.pi, periodized=True, **kw)
 
   @property
   def num_bijector_params(self) -> int:
@@ -60,7 +69,7 @@ def param_spec(cfg: FlowConfig) -> List[Tuple[str, str, Tuple[int, ...]]]:
     for d in range(1, cfg.dim):
       name = f"layer{l}_d{d}"
       for m in range(cfg.mlp_num_layers):
-        rows = (1 + d) if m == 0 else H
+        rows = ((2 if cfg.periodized else 1) * (1 + d)) if m == 0 else H
         spec.append((f"mlp_{name}/~/linear_{m}", "w", (rows, H)))
         spec.append((f"mlp_{name}/~/linear_{m}", "b", (H,)))
       spec.append((f"linear_out_{name}", "w", (H, P)))

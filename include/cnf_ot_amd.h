@@ -60,6 +60,14 @@ typedef struct CnfConfig {
   float range_max;        /* +10  (flows.py:128)                    */
   float min_bin_size;     /* 1e-4 (distrax default)                 */
   float min_knot_slope;   /* 1e-4 (flows.py:130)                    */
+  int32_t periodized;     /* 0; 1 = RQSFlow(periodized=True), flows.py:58-64,127-131: the conditioner MLP sees
+                           * [sin(x), cos(x)] of its input x = [c, v] (first linear layer: 2 (1 + d) rows, sin
+                           * rows first), boundary_slopes='circular' (the last knot slope is the first); the
+                           * caller sets range_min = 0, range_max = 2 pi (a float here: 6.2831855, 1.7e-7 above the reference's
+                           * double).  Flow functions only (forward / inverse
+                           * / log_prob / sample_logprob, float32 and float64): the loss, gradient and
+                           * vector-Jacobian entry points return CNF_ERR_UNSUPPORTED -- no reference call site
+                           * passes periodized=True. */
 } CnfConfig;
 
 typedef struct CnfModel CnfModel;

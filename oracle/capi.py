@@ -17,6 +17,7 @@ class _Cfg(ctypes.Structure):
     ("M", ctypes.c_int32), ("K", ctypes.c_int32),
     ("range_min", ctypes.c_double), ("range_max", ctypes.c_double),
     ("min_bin_size", ctypes.c_double), ("min_knot_slope", ctypes.c_double),
+    ("periodized", ctypes.c_int32),
   ]
 
 
@@ -33,10 +34,18 @@ class OracleConfig:
   range_max: float = 10.0
   min_bin_size: float = 1e-4
   min_knot_slope: float = 1e-4
+  # flows.py:58-64,127-131: sin/cos features of the conditioner input, boundary_slopes='circular'; the caller sets
+  # the range to [0, 2 pi] (OracleConfig.torus)
+  periodized: bool = False
+
+  @staticmethod
+  def torus(**kw):
+    import math
+    return OracleConfig(range_min=0.0, range_max=2.0 * math.pi, periodized=True, **kw)
 
   def c(self):
     return _Cfg(self.D, self.L, self.H, self.M, self.K, self.range_min,
-                self.range_max, self.min_bin_size, self.min_knot_slope)
+                self.range_max, self.min_bin_size, self.min_knot_slope, 1 if self.periodized else 0)
 
 
 def build_library(force: bool = False) -> str:

@@ -27,7 +27,8 @@ int cnf_oracle_check_cfg(const cnf_oracle_cfg *g) {
 size_t cnf_oracle_param_count(const cnf_oracle_cfg *g) {
   size_t H = (size_t)g->H, P = (size_t)(3 * g->K + 1), n = P;
   for (int d = 1; d < g->D; ++d)
-    n += (size_t)g->L * ((size_t)(1 + d) * H + H + (size_t)(g->M - 1) * (H * H + H) + H * P + P);
+    n += (size_t)g->L * ((size_t)(g->periodized ? 2 : 1) * (size_t)(1 + d) * H + H +
+                         (size_t)(g->M - 1) * (H * H + H) + H * P + P);
   return n;
 }
 
@@ -55,7 +56,11 @@ int cnf_oracle_num_threads(void) {
 #define R_LOG1P log1p
 #define R_SQRT sqrt
 #define R_FABS fabs
+#define R_SIN sin
+#define R_COS cos
 #include "cnf_oracle_impl.h"
+#undef R_SIN
+#undef R_COS
 #undef REAL
 #undef FN
 #undef R_EXP
@@ -72,9 +77,13 @@ int cnf_oracle_num_threads(void) {
 #define R_LOG1P log1pf
 #define R_SQRT sqrtf
 #define R_FABS fabsf
+#define R_SIN sinf
+#define R_COS cosf
 #include "cnf_oracle_impl.h"
 #undef REAL
 #undef FN
+#undef R_SIN
+#undef R_COS
 #undef R_EXP
 #undef R_LOG
 #undef R_LOG1P

@@ -29,6 +29,8 @@ typedef struct {
   double range_min, range_max;   /* flows.py:127-128: -10, 10         */
   double min_bin_size;           /* distrax default 1e-4              */
   double min_knot_slope;         /* flows.py:130: 1e-4                */
+  int32_t periodized;            /* flows.py:58-64,127-131: sin/cos features of the conditioner input,
+                                    range [0, 2 pi], boundary_slopes='circular' (last knot slope := first) */
 } cnf_oracle_cfg;
 
 int cnf_oracle_check_cfg(const cnf_oracle_cfg *g);

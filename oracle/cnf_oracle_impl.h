@@ -36,7 +36,8 @@
 
 static size_t FN(cond_size)(const cnf_oracle_cfg *g, int d) {
   size_t H = (size_t)g->H, P = (size_t)(3 * g->K + 1);
-  return (size_t)(1 + d) * H + H + (size_t)(g->M - 1) * (H * H + H) + H * P + P;
+  /* periodized: the MLP sees [sin(c, v), cos(c, v)] (flows.py:58-64, num_fourier_feat = 1): 2 (1 + d) inputs */
+  return (size_t)(g->periodized ? 2 : 1) * (size_t)(1 + d) * H + H + (size_t)(g->M - 1) * (H * H + H) + H * P + P;
 }
 
 static size_t FN(cond_offset)(const cnf_oracle_cfg *g, int l, int d) {
@@ -50,9 +51,19 @@ static size_t FN(cond_offset)(const cnf_oracle_cfg *g, int l, int d) {
 
 /* distrax _normalize_bin_sizes / _normalize_knot_slopes / __init__ knot build
  * (constants fixed by flows.py:124-132). */
+static void FN(rqs_knots_bs)(const REAL *theta, int K, REAL lo, REAL hi,
+                             REAL min_bin, REAL min_slope, int circular, REAL *xk, REAL *yk,
+                             REAL *dl);
 static void FN(rqs_knots)(const REAL *theta, int K, REAL lo, REAL hi,
                           REAL min_bin, REAL min_slope, REAL *xk, REAL *yk,
                           REAL *dl) {
+  FN(rqs_knots_bs)(theta, K, lo, hi, min_bin, min_slope, 0, xk, yk, dl);
+}
+/* circular: distrax boundary_slopes='circular' (flows.py:131): the unnormalized slope of the last knot is
+ * replaced by that of the first before normalisation, so f'(range_min) = f'(range_max). */
+static void FN(rqs_knots_bs)(const REAL *theta, int K, REAL lo, REAL hi,
+                             REAL min_bin, REAL min_slope, int circular, REAL *xk, REAL *yk,
+                             REAL *dl) {
   REAL total = (hi - lo) - (REAL)K * min_bin;
   for (int part = 0; part < 2; ++part) {
     const REAL *u = theta + part * K;
@@ -73,7 +84,7 @@ static void FN(rqs_knots)(const REAL *theta, int K, REAL lo, REAL hi,
   /* offset = log(exp(1 - m) - 1); softplus(u + offset) + m */
   REAL offset = R_LOG(R_EXP((REAL)1 - min_slope) - (REAL)1);
   for (int k = 0; k <= K; ++k) {
-    REAL v = theta[2 * K + k] + offset;
+    REAL v = theta[2 * K + (circular && k == K ? 0 : k)] + offset;
     REAL sp = (v > 0 ? v : (REAL)0) + R_LOG1P(R_EXP(-R_FABS(v)));
     dl[k] = sp + min_slope;
   }
@@ -141,12 +152,22 @@ static void FN(rqs_inv)(REAL y, const REAL *xk, const REAL *yk, const REAL *dl,
  * hk.nets.MLP(hidden, activate_final=True, relu) then hk.Linear(P). */
 static void FN(conditioner)(const cnf_oracle_cfg *g, const REAL *p, int d,
                             REAL c, const REAL *v, REAL *theta) {
-  int H = g->H, P = 3 * g->K + 1, nin = 1 + d;
+  int H = g->H, P = 3 * g->K + 1, nin = (g->periodized ? 2 : 1) * (1 + d);
   REAL h[CNF_ORACLE_MAX_H], h2[CNF_ORACLE_MAX_H];
+  REAL in[2 * (CNF_ORACLE_MAX_D + 1)];
   const REAL *W = p, *b = p + (size_t)nin * H;
+  if (g->periodized) {      /* flows.py:58-64: concatenate([sin(x)], [cos(x)]) of x = [c, v] */
+    in[0] = R_SIN(c); in[1 + d] = R_COS(c);
+    for (int i = 0; i < d; ++i) { in[1 + i] = R_SIN(v[i]); in[2 + d + i] = R_COS(v[i]); }
+  } else {
+    in[0] = c;
+    for (int i = 0; i < d; ++i) in[1 + i] = v[i];
+  }
   for (int j = 0; j < H; ++j) {
-    REAL acc = b[j] + c * W[j];
-    for (int i = 0; i < d; ++i) acc += v[i] * W[(size_t)(1 + i) * H + j];
+    REAL acc = b[j];
+    /* (summed in the order c, v_0, v_1, ...: the non-periodized results stay bit-identical) */
+    acc = b[j] + in[0] * W[j];
+    for (int i = 1; i < nin; ++i) acc += in[i] * W[(size_t)i * H + j];
     h[j] = acc > 0 ? acc : (REAL)0;
   }
   p = b + H;
@@ -198,8 +219,8 @@ static void FN(forward1)(const cnf_oracle_cfg *g, const REAL *params,
         FN(conditioner)(g, params + FN(cond_offset)(g, l, d), d, c, v, theta);
         th = theta;
       }
-      FN(rqs_knots)(th, K, (REAL)g->range_min, (REAL)g->range_max,
-                    (REAL)g->min_bin_size, (REAL)g->min_knot_slope, xk, yk, dl);
+      FN(rqs_knots_bs)(th, K, (REAL)g->range_min, (REAL)g->range_max,
+                       (REAL)g->min_bin_size, (REAL)g->min_knot_slope, g->periodized, xk, yk, dl);
       REAL ld;
       FN(rqs_inv)(u[i], xk, yk, dl, K, &o[i], &ld);
       total += ld;
@@ -235,8 +256,8 @@ static void FN(inverse1)(const cnf_oracle_cfg *g, const REAL *params,
         FN(conditioner)(g, params + FN(cond_offset)(g, l, d), d, c, v, theta);
         th = theta;
       }
-      FN(rqs_knots)(th, K, (REAL)g->range_min, (REAL)g->range_max,
-                    (REAL)g->min_bin_size, (REAL)g->min_knot_slope, xk, yk, dl);
+      FN(rqs_knots_bs)(th, K, (REAL)g->range_min, (REAL)g->range_max,
+                       (REAL)g->min_bin_size, (REAL)g->min_knot_slope, g->periodized, xk, yk, dl);
       REAL ld;
       FN(rqs_fwd)(u[i], xk, yk, dl, K, &o[i], &ld);
       total += ld;

@@ -25,10 +25,13 @@ def normalize_bin_sizes(u, total, min_bin):
   return e / e.sum(axis=-1, keepdims=True) * (total - u.shape[-1] * min_bin) + min_bin
 
 
-def rqs_tables(theta, lo, hi, min_bin=1e-4, min_slope=1e-4):
-  """theta [...,3K+1] -> x_pos, y_pos, slopes, each [...,K+1]."""
+def rqs_tables(theta, lo, hi, min_bin=1e-4, min_slope=1e-4, circular=False):
+  """theta [...,3K+1] -> x_pos, y_pos, slopes, each [...,K+1].  circular: distrax
+  boundary_slopes='circular' (flows.py:131): the last unnormalized slope := the first."""
   theta = np.asarray(theta, dtype=np.float64)
   K = (theta.shape[-1] - 1) // 3
+  if circular:
+    theta = np.concatenate([theta[..., :-1], theta[..., 2 * K:2 * K + 1]], -1)
   w = normalize_bin_sizes(theta[..., :K], hi - lo, min_bin)
   h = normalize_bin_sizes(theta[..., K:2 * K], hi - lo, min_bin)
   pad_lo = np.full(theta.shape[:-1] + (1,), lo)
@@ -96,8 +99,9 @@ class NumpyFlow:
   """The flow built from a flat parameter vector (layout: cnf_oracle_impl.h)."""
 
   def __init__(self, flat, D=2, L=2, H=16, M=2, K=5, lo=-10.0, hi=10.0,
-               min_bin=1e-4, min_slope=1e-4):
+               min_bin=1e-4, min_slope=1e-4, periodized=False):
     self.D, self.L, self.H, self.M, self.K = D, L, H, M, K
+    self.periodized = periodized          # flows.py:58-64 (sin / cos features), :127-131 (range, circular slopes)
     self.lo, self.hi, self.min_bin, self.min_slope = lo, hi, min_bin, min_slope
     P = 3 * K + 1
     flat = np.asarray(flat, dtype=np.float64).reshape(-1)
@@ -107,7 +111,7 @@ class NumpyFlow:
     for l in range(L):
       for d in range(1, D):
         layers = []
-        nin = 1 + d
+        nin = (2 if periodized else 1) * (1 + d)
         for m in range(M):
           rows = nin if m == 0 else H
           W = flat[off:off + rows * H].reshape(rows, H); off += rows * H
@@ -134,8 +138,10 @@ class NumpyFlow:
       theta = np.broadcast_to(self.first, (B, 3 * self.K + 1))
     else:
       inp = np.concatenate([c[:, None], known[:, perm[:d]]], axis=1)
+      if self.periodized:
+        inp = np.concatenate([np.sin(inp), np.cos(inp)], axis=1)
       theta = self.conditioner(l, d, inp)
-    return rqs_tables(theta, self.lo, self.hi, self.min_bin, self.min_slope)
+    return rqs_tables(theta, self.lo, self.hi, self.min_bin, self.min_slope, circular=self.periodized)
 
   def _c(self, c, B):
     c = np.asarray(c, dtype=np.float64).reshape(-1)

@@ -91,8 +91,13 @@ def test_rqsflow_signature_and_argument_errors():
   assert m.cfg == FlowConfig(dim=2)
   assert cnf_ot_amd.Flow._fields == ("log_prob", "sample", "sample_and_log_prob", "forward", "inverse",
                                      "forward_jac", "inverse_jac", "gauge_potential")   # flows.py:215-219
-  with pytest.raises(NotImplementedError):
-    cnf_ot_amd.RQSFlow((2,), 2, [16, 16], 5, periodized=True)
+  # periodized=True (flows.py:58-64,127-131): the torus model -- range [0, 2 pi], and a first linear layer with
+  # 2 (1 + d) rows (sin and cos of every conditioner input)
+  mp = cnf_ot_amd.RQSFlow((3,), 2, [16, 16], 5, periodized=True)
+  assert mp.cfg.periodized and mp.cfg.range_min == 0.0 and abs(mp.cfg.range_max - 2 * np.pi) < 1e-12
+  shapes = {(mod, name): shape for mod, name, shape in param_spec(mp.cfg)}
+  assert shapes[("mlp_layer0_d1/~/linear_0", "w")] == (4, 16) and shapes[("mlp_layer1_d2/~/linear_0", "w")] == (6, 16)
+  assert mp.cfg.param_count() == FlowConfig(dim=3).param_count() + 2 * (2 + 3) * 16
   with pytest.raises(NotImplementedError):
     cnf_ot_amd.RQSFlow((2,), 2, [16, 32], 5)
 

@@ -719,6 +719,61 @@ def test_reference_call_surface(dev):
   assert _err(y, y_ref).max() <= TOL_Y
 
 
+@pytest.mark.parametrize("D", [1, 2, 3])
+def test_periodized_flow_vs_oracle(dev, D):
+  """RQSFlow(periodized=True) (flows.py:58-64,127-131; no reference call site passes it): sin / cos features of
+  the conditioner input, splines on [0, 2 pi] with circular boundary slopes.  float32 kernels against the float64
+  oracle at the plain-fp32 bars, the float64 kernels at 1e-11, both directions, points inside and outside the
+  range; the loss / gradient entry points refuse the configuration."""
+  import oracle
+  from cnf_ot_amd import FlowConfig, FlowEngine, RQSFlow, Params
+  fcfg = FlowConfig.torus(dim=D)
+  # (the C ABI carries the range as float32: the oracle gets the same rounded 2 pi, 1.7e-7 above the double)
+  ocfg = oracle.OracleConfig(D=D, range_min=0.0, range_max=float(np.float32(2 * np.pi)), periodized=True)
+  n = oracle.param_count(ocfg)
+  assert n == fcfg.param_count()
+  rng = np.random.default_rng(300 + D)
+  params = rng.normal(0, 0.3, n).astype(np.float32).astype(np.float64)
+  B = 5000
+  x = rng.uniform(0.0, 2 * np.pi, size=(B, D)).astype(np.float32)
+  x[0] = -0.5; x[1] = 2 * np.pi + 0.25; x[2] = 0.0          # linear tails and the boundary itself
+  ts = np.array([0.3, 4.1])                                   # two slices
+  c_host = np.repeat(ts, B // 2)
+  eng = _engine(fcfg, params, dev)
+  y, fldj = eng.forward_logdet(_t(x, dev), _t(ts, dev))
+  y_ref, fldj_ref = oracle.forward_logdet(ocfg, params, x.astype(np.float64), c_host)
+  print(f"\n[periodized D={D}] forward max|dy|={_err(y, y_ref).max():.2e} max|dlogdet|={_err(fldj, fldj_ref).max():.2e}")
+  assert _err(y, y_ref).max() <= TOL_Y and _err(fldj, fldj_ref).max() <= TOL_LD * max(1, D)
+  y_in = y_ref.astype(np.float32)
+  xb, ildj = eng.inverse_logdet(_t(y_in, dev), _t(ts, dev))
+  xb_ref, ildj_ref = oracle.inverse_logdet(ocfg, params, y_in.astype(np.float64), c_host)
+  assert _err(xb, xb_ref).max() <= TOL_Y and _err(ildj, ildj_ref).max() <= TOL_LD * max(1, D)
+  lp = eng.log_prob(_t(y_in, dev), _t(ts, dev))
+  lp_ref = oracle.log_prob(ocfg, params, y_in.astype(np.float64), c_host)
+  assert _err(lp, lp_ref).max() <= TOL_LP_FP32_MAX * max(1, D)
+  # float64 kernels
+  yd, ld = eng.forward_logdet(torch.from_numpy(x.astype(np.float64)).to(dev), torch.from_numpy(ts).to(dev))
+  assert yd.dtype == torch.float64
+  assert _err(yd, y_ref).max() <= 1e-11 and _err(ld, fldj_ref).max() <= 1e-10
+  # the torus conditions: y stays in the range, the conditioner is 2 pi-periodic in c
+  inside = (x > 0).all(1) & (x < 2 * np.pi).all(1)
+  yi = y[torch.from_numpy(inside).to(dev)]
+  assert yi.min().item() >= 0.0 and yi.max().item() <= 2 * np.pi + 1e-6
+  if D >= 2:
+    y2, _ = eng.forward_logdet(_t(x, dev), _t(ts + 2 * np.pi, dev))
+    assert (y2 - y).abs().max().item() <= 5e-5
+  # the model object: init is the identity, sampling and log_prob agree with each other
+  model = RQSFlow(event_shape=(D,), num_layers=2, hidden_sizes=[16, 16], num_bins=5, periodized=True)
+  p0 = model.init(0)
+  s, lps = model.apply.sample_and_log_prob(p0, cond=torch.full((64, 1), 0.2, device=dev), seed=3, sample_shape=(64,))
+  lpv = model.apply.log_prob(p0, s, cond=torch.tensor([0.2], device=dev))
+  assert (lps - lpv).abs().max().item() <= 1e-4
+  # losses / gradients: refused, loudly
+  from cnf_ot_amd import applications as app
+  with pytest.raises((RuntimeError, NotImplementedError)):
+    app.kinetic_loss_fn(model, D, 0.01, Params.random(model.cfg, 0.1, seed=1, device=dev), 0.5, 7, 256)
+
+
 def test_wide_event_dimension(dev):
   """Large D: the LDS tile (2 x D x 256 or 512 floats) needs the > 64 KB opt-in
   and, beyond that, one sample per lane."""
