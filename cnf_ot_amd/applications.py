@@ -131,8 +131,16 @@ def _source_samples(ctx, z, start, count, n_global, source):
 
 def _kl_sum(ctx, T, cond, batch_size, source, coef):
   z, start, count = ctx.noise(batch_size)
-  s1 = _source_samples(ctx, z, start, count, batch_size, source)
-  samples = s1 * ((T - cond) / T) + z * (cond / T)      # target N(0,I) drawn from the same key
+  key = ("source", batch_size, source)       # the same key draws the same source samples for every condition
+  s1 = ctx._noise.get(key)
+  if s1 is None:
+    s1 = ctx._noise[key] = _source_samples(ctx, z, start, count, batch_size, source)
+  if cond == 0.0:
+    samples = s1
+  elif cond == T:
+    samples = z
+  else:
+    samples = s1 * ((T - cond) / T) + z * (cond / T)      # target N(0,I) drawn from the same key
   return ctx.terms(_spec(_capi.TERM_NEG_LOGPROB), samples.contiguous(), [cond], count, coef)
 
 

@@ -90,10 +90,28 @@ class Params(dict):
       raise ValueError(f"flat has {flat.numel()} values, config needs {cfg.param_count()}")
     self.cfg = cfg
     self.flat = flat
-    off = 0
-    for mod, name, shape, n in _spec_sizes(cfg):
-      self.setdefault(mod, {})[name] = flat[off:off + n].view(*shape)
-      off += n
+    self._built = False        # the tree of views is built on first use: an optimiser step only needs `flat`
+
+  def _build(self):
+    if not self._built:
+      self._built = True
+      off = 0
+      for mod, name, shape, n in _spec_sizes(self.cfg):
+        dict.setdefault(self, mod, {})[name] = self.flat[off:off + n].view(*shape)
+        off += n
+    return self
+
+  def __getitem__(self, k): return dict.__getitem__(self._build(), k)
+  def __iter__(self): return dict.__iter__(self._build())
+  def __len__(self): return dict.__len__(self._build())
+  def __contains__(self, k): return dict.__contains__(self._build(), k)
+  def keys(self): return dict.keys(self._build())
+  def items(self): return dict.items(self._build())
+  def values(self): return dict.values(self._build())
+  def get(self, k, default=None): return dict.get(self._build(), k, default)
+  def __repr__(self): return dict.__repr__(self._build())
+  def __eq__(self, other): return dict.__eq__(self._build(), other)
+  __hash__ = None
 
   @classmethod
   def zeros(cls, cfg: FlowConfig, device="cpu") -> "Params":

@@ -14,4 +14,4 @@ print("step ms (async issue + final sync):", (time.perf_counter() - t0) / 200 * 
 pr = cProfile.Profile(); pr.enable()
 for i in range(200): upd(p, i + 1000, 5000.0, st)
 torch.cuda.synchronize(); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28); print(s.getvalue()[:5000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(22); print(s.getvalue()[:5000])
