@@ -89,6 +89,12 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
   __shared__ int bad[PWL_NPIECE];                  // piece needs the general spline evaluation
   __shared__ double urefs[PWL_CHUNK];
   __shared__ int icnt[17], ioff[17];               // finite roots per first-layer interval, and their prefix sums
+  // Second-layer pre-activations P u + Q of every (first-layer interval, unit): inside an interval the first layer's
+  // activity pattern is fixed, so every piece of the interval has these coefficients -- stage 1 below looks them up
+  // instead of redoing the 16-term sums per (piece, unit).  biv[q]: the interval of the piece to the LEFT of
+  // breakpoint q.
+  __shared__ double IPQ[17 * PWL_H * 2];
+  __shared__ int biv[PWL_NPIECE];
   const int tid = threadIdx.x;
   const int slice = blockIdx.x / L, l = blockIdx.x % L;
   const float* w = weights + l * per_layer;         // D = 2: the layer's only conditioner (d = 1)
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
   const int iv = tid / PWL_H, kk = tid % PWL_H;        // interval, second-layer unit (tid < 17 * 16)
   if (tid < 17 * PWL_H) {
     const double lo = iv == 0 ? -INF : sbp[iv - 1], hi = iv == PWL_H ? INF : sbp[iv];
-    if (lo < hi && lo < INF) {
+    if (lo < INF) {             // (an interval between tied breakpoints is empty but still owns a zero-width piece)
       const double u = test_point(lo, hi);
       double P = 0.0, Q = bb1[kk];
       for (int j = 0; j < PWL_H; ++j) {
@@ -133,7 +139,8 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
         P += on * a1[j];
         Q += on * b1v[j];
       }
-      if (P != 0.0) { const double r = -Q / P; if (r > lo && r < hi) root = r; }
+      IPQ[2 * tid] = P; IPQ[2 * tid + 1] = Q;
+      if (lo < hi && P != 0.0) { const double r = -Q / P; if (r > lo && r < hi) root = r; }
     }
     candu[PWL_H + tid] = root;
   }
@@ -160,8 +167,14 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
     ioff[tid] = sum;
   }
   __syncthreads();
-  if (tid < 17 * PWL_H && root < INF) cand[iv + ioff[iv] + rank_in] = root;       // iv first-layer breakpoints precede it
-  if (tid < PWL_H && sbp[tid] < INF) cand[tid + ioff[tid] + icnt[tid]] = sbp[tid];
+  if (tid < 17 * PWL_H && root < INF) {          // iv first-layer breakpoints precede it
+    cand[iv + ioff[iv] + rank_in] = root;
+    biv[iv + ioff[iv] + rank_in] = iv;
+  }
+  if (tid < PWL_H && sbp[tid] < INF) {
+    cand[tid + ioff[tid] + icnt[tid]] = sbp[tid];
+    biv[tid + ioff[tid] + icnt[tid]] = tid;       // the piece that ends at the t-th sorted first-layer breakpoint
+  }
   int n1 = 0;
   for (int j = 0; j < PWL_H; ++j) n1 += sbp[j] < INF ? 1 : 0;
   const int n = n1 + ioff[16] + icnt[16];             // finite breakpoints; pieces 0 .. n
@@ -180,12 +193,8 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
       const int p = base + (t >> 4), k = t & 15;
       const double lo = p == 0 ? -INF : cand[p - 1], hi = p < n ? cand[p] : INF;
       const double u = test_point(lo, hi);
-      double P = 0.0, Q = bb1[k];
-      for (int j = 0; j < PWL_H; ++j) {
-        const double on = a1[j] * u + b1v[j] > 0.0 ? W1[j * PWL_H + k] : 0.0;
-        P += on * a1[j];
-        Q += on * b1v[j];
-      }
+      const int ivp = p < n ? biv[p] : n1;          // the last piece lies beyond every finite first-layer breakpoint
+      const double P = IPQ[2 * (ivp * PWL_H + k)], Q = IPQ[2 * (ivp * PWL_H + k) + 1];
       const bool act = P * u + Q > 0.0;
       PQ[2 * t] = act ? P : 0.0;
       PQ[2 * t + 1] = act ? Q : 0.0;
@@ -261,42 +270,54 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
   // against two breakpoints unconditionally and loop only in such cells (cell 0 / the last cell also serve every
   // u beyond the grid).  PWL_G_GENERAL: the cell touches a piece that needs the general spline evaluation, or is
   // one of the two outermost cells.
-  // Four cells per thread, their binary searches interleaved (a fixed 9 halvings cover n <= 289): the step is
-  // a chain of dependent LDS reads, and four independent chains cost what one does.
+  // lo_ of cell g = the number of breakpoints b <= x_g = GMIN + g / GSCALE - 1e-4 -- counted from the breakpoints'
+  // side: breakpoint b is below the left edge of every cell from g_b = ceil((b + 1e-4 - GMIN) GSCALE) on, so each
+  // breakpoint adds one at g_b and lo_ is the running sum (a block scan: four consecutive cells per thread, a
+  // shuffle scan inside the wave, the eight wave totals through LDS).  Round 2's first version searched every cell
+  // through nine dependent LDS reads: the largest phase of the kernel.  A cell index off by one through rounding is
+  // covered by the 1e-4 the edge is pulled in by (see above).
+  int* delta = reinterpret_cast<int*>(PQ);               // PQ is free again: 2 049 + 8 ints
+  static_assert(sizeof(double) * PWL_CHUNK * PWL_H * 2 >= sizeof(int) * (PWL_NG + 16), "scratch for the grid scan");
   constexpr int CPT = 4;
-  static_assert(PWL_NG % CPT == 0 && PWL_NPIECE <= 512, "grid step: 9 halvings");
-  for (int g0 = tid; g0 < PWL_NG / CPT; g0 += blockDim.x) {
-    int lo_[CPT], hi_[CPT];
-    double x[CPT];
+  static_assert(PWL_NG == 512 * CPT, "one thread owns four consecutive cells (512 threads)");
+  for (int g = tid; g < PWL_NG + 16; g += blockDim.x) delta[g] = 0;
+  __syncthreads();
+  for (int p = tid; p < n; p += blockDim.x) {
+    const double gb = ceil((cand[p] + 1e-4 - (double)PWL_GMIN) * (double)PWL_GSCALE);
+    // (cell 0 serves every u below the grid and searches from piece 0: breakpoints below the grid count from cell 1)
+    const int g0 = gb < 1.0 ? 1 : (gb >= (double)PWL_NG ? PWL_NG : (int)gb);
+    atomicAdd(&delta[g0], 1);                             // (slot PWL_NG: breakpoints beyond the grid, never summed)
+  }
+  __syncthreads();
+  {
+    const int g0 = tid * CPT;
+    int c0 = delta[g0], c1 = c0 + delta[g0 + 1], c2 = c1 + delta[g0 + 2], c3 = c2 + delta[g0 + 3];
+    int run = c3;                                         // inclusive scan of the threads' totals over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(run, off, 64);
+      if ((tid & 63) >= off) run += v;
+    }
+    int* wtot = delta + PWL_NG + 8;                       // eight wave totals
+    __syncthreads();                                      // (everybody has read its delta entries)
+    if ((tid & 63) == 63) wtot[tid >> 6] = run;
+    __syncthreads();
+    int before = run - c3;                                // exclusive within the wave
+    for (int w2 = 0; w2 < (tid >> 6); ++w2) before += wtot[w2];
+    const int cnt[CPT] = {before + c0, before + c1, before + c2, before + c3};
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      const int g = g0 + i * (PWL_NG / CPT);
-      x[i] = (double)PWL_GMIN + (double)g / (double)PWL_GSCALE - 1e-4;
-      lo_[i] = 0;
-      hi_[i] = g == 0 ? 0 : n;                  // cell 0 also serves every u below the grid: search from piece 0
-    }
-    for (int step = 0; step < 9; ++step) {
-#pragma unroll
-      for (int i = 0; i < CPT; ++i) {
-        const int mid = (lo_[i] + hi_[i]) >> 1;
-        const bool open = lo_[i] < hi_[i];
-        const bool le = cand[open ? mid : 0] <= x[i];
-        lo_[i] = open && le ? mid + 1 : lo_[i];
-        hi_[i] = open && !le ? mid : hi_[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int g = g0 + i * (PWL_NG / CPT);
+      const int g = g0 + i;
+      const int lo_ = g == 0 ? 0 : cnt[i];
       const double xr = g == PWL_NG - 1 ? INF : (double)PWL_GMIN + (double)(g + 1) / (double)PWL_GSCALE + 1e-4;
       int mark = (g == 0 || g == PWL_NG - 1) ? 1 : 0;
-      for (int p = lo_[i]; p <= n && !mark; ++p) {          // pieces lo_ .. the one holding the cell's right edge
+      for (int p = lo_; p <= n && !mark; ++p) {          // pieces lo_ .. the one holding the cell's right edge
         mark |= bad[p];
         if (p < n && cand[p] > xr) break;
       }
-      const bool many = lo_[i] + 2 < n && cand[lo_[i] + 2] <= xr;      // a third breakpoint a sample of the cell can pass
+      const bool many = lo_ + 2 < n && cand[lo_ + 2] <= xr;      // a third breakpoint a sample of the cell can pass
       reinterpret_cast<uint16_t*>(T + PWL_OFF_GRID)[g] =
-          (uint16_t)((uint32_t)lo_[i] | (mark ? PWL_G_GENERAL : 0u) | (many ? PWL_G_MANY : 0u));
+          (uint16_t)((uint32_t)lo_ | (mark ? PWL_G_GENERAL : 0u) | (many ? PWL_G_MANY : 0u));
     }
   }
 }

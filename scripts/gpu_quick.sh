@@ -1,7 +1,7 @@
 #!/bin/bash
 # quick A/B on the metric kernel: selected parity tests (minimal build is enough) + the headline without extras
 # scripts/gpu_quick.sh <tag> [pytest -k expression]
-TAG=${1:-q}; K=${2:-"piecewise or table_path or config2 or per_sample or never_allocate or capturable or wild"}
+TAG=${1:-q}; K=${2:-"piecewise or table_path or table_rows or config2 or per_sample or never_allocate or capturable or wild"}
 mkdir -p gpurun_out
 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -s -k "$K" > gpurun_out/pytest_$TAG.log 2>&1
 rc=$?; echo "pytest rc=$rc"; grep -E "^\[pwl|passed|failed|FAILED|rror" gpurun_out/pytest_$TAG.log | tail -30
