@@ -61,3 +61,33 @@ def test_piece_count_of_the_bench_parameters():
     for c in (0.0, 0.5, 1.0):
       n = pt.build_table(w, c)[0].size
       assert 8 <= n <= 128, n
+
+
+@pytest.mark.parametrize("kind", ["small", "large", "zigzag", "dead_units"])
+def test_weight_gradient_from_per_piece_statistics(kind):
+  """on a piece of the conditioner tables both ReLU patterns are constant, so the weight
+  gradient is linear in A = sum g and B = sum u g per piece.  oracle/pwl_grad.py restates that algebra; here it is
+  checked against plain per-sample backprop through the network (and the input adjoint against the piece slopes)."""
+  from oracle import pwl_grad as pg
+  rng = np.random.default_rng(11)
+  for trial in range(4):
+    if kind == "small":
+      w = rng.normal(0, 0.2, N_W)
+    elif kind == "large":
+      w = rng.normal(0, 1.0, N_W)
+    elif kind == "zigzag":
+      w = _zigzag(rng)
+    else:
+      w = rng.normal(0, 0.5, N_W)
+      w[16:32][rng.integers(0, 2, 16) == 0] = 0.0
+    c = float(rng.uniform(0, 1))
+    u = rng.normal(0, 3.0, 4000)
+    g = rng.normal(size=(4000, 16))
+    table = pt.build_table(w, c)
+    ref, du_ref = pg.grad_per_sample(w, c, u, g)
+    A, B, piece = pg.piece_statistics(table, u, g)
+    got = pg.grad_from_statistics(w, c, table, A, B)
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 1e-9 * scale, (kind, trial, np.abs(got - ref).max() / scale)
+    du = pg.input_adjoint(table, u, g, piece)
+    assert np.abs(du - du_ref).max() <= 1e-9 * np.abs(du_ref).max()
