@@ -85,6 +85,8 @@ struct CnfModel {
   int use_dpar;           // 1: wave-per-dimension kernel for small base -> data launches at dim >= 3
   // table workspaces [sets][L][PWL_TBL], one per stream (calls on different streams never share one).
   // Allocated ONLY by cnf_model_reserve; the compute entry points look theirs up and never allocate.
+  // cnf_grad_enable: per-piece gradient statistics of the table backward (cnf_grad.hip), PWL_STAT_SLICES slices
+  float* pwl_stats;
   struct PwlWorkspace { float* tables; int64_t sets; uint32_t epoch; };
   std::mutex pwl_mu;
   std::unordered_map<void*, PwlWorkspace> pwl_ws;
@@ -147,6 +149,11 @@ static inline int wait_for_params(CnfModel* m, hipStream_t stream) {
     if (hipStreamWaitEvent(stream, m->prep_event, 0) != hipSuccess) return CNF_ERR_HIP;
   return CNF_OK;
 }
+
+// cnf_flow.hip: builds the dim-2 conditioner tables (cnf_pwl.h) of n slices -- conditions c[0 .. n) on the device --
+// into the stream's reserved workspace and returns them; CNF_ERR_UNSUPPORTED if the configuration has no table path
+// or the stream's reservation (cnf_model_reserve) is smaller than n.  Used by the table form of cnf_pass_vjp.
+int cnf_internal_build_tables(CnfModel* m, hipStream_t stream, const float* c, int64_t n, float** tables);
 
 static inline cnf::ModelArgs model_args(const CnfModel* m) {
   cnf::ModelArgs a;

@@ -550,19 +550,6 @@ __global__ void cond_uniform_kernel(const float* __restrict__ c, int64_t B, uint
   if (__syncthreads_or(diff) && threadIdx.x == 0) *flag = epoch;
 }
 
-// Stage the L tables of (set, slice) into LDS: header arrays + the rows in use, at most PWL_LROWS.
-template <int LROWS = PWL_LROWS>
-__device__ __forceinline__ void pwl_stage(float* tbl, const float* __restrict__ g0, int L, int tid, int nthreads) {
-  for (int l = 0; l < L; ++l) {
-    const float* g = g0 + (int64_t)l * PWL_TBL;
-    const int n = __float_as_int(g[PWL_N_SLOT]);                       // pieces 0 .. n
-    const int rows = n + 1 < LROWS ? n + 1 : LROWS;
-    const f4* src = reinterpret_cast<const f4*>(g);
-    f4* dst = reinterpret_cast<f4*>(tbl + l * pwl_ltbl(LROWS));
-    for (int i = tid; i < (PWL_OFF_PIECE + rows * PWL_ROW) / 4; i += nthreads) dst[i] = src[i];
-  }
-}
-
 // The dim-2 flow on one sample pair held in registers, conditioner from the tables (`tbl`: the L
 // tables in LDS, `gtbl`: the same in global memory for rows past the LDS window).  In place;
 // returns the accumulated log|det J| of the direction.
@@ -1290,6 +1277,7 @@ extern "C" void cnf_model_destroy(CnfModel* m) {
   if (!m) return;
   if (m->prep) (void)hipFree(m->prep);
   if (m->grad_slabs) (void)hipFree(m->grad_slabs);
+  if (m->pwl_stats) (void)hipFree(m->pwl_stats);
   for (auto& kv : m->pwl_ws) if (kv.second.tables) (void)hipFree(kv.second.tables);
   if (m->prep_event) (void)hipEventDestroy(m->prep_event);
   prof_clear(m);
@@ -1698,6 +1686,18 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
     ps.done();
   }
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+int cnf_internal_build_tables(CnfModel* m, hipStream_t stream, const float* c, int64_t n, float** tables) {
+  if (!pwl_config_ok(m) || n < 1) return CNF_ERR_UNSUPPORTED;
+  int64_t sets = 0;
+  pwl_workspace(m, stream, tables, &sets);
+  if (sets < n) return CNF_ERR_UNSUPPORTED;
+  const int L = m->cfg.num_layers;
+  const double sp_offset = log(exp(1.0 - (double)m->cfg.min_knot_slope) - 1.0);
+  hipLaunchKernelGGL(cnf::pwl_build_kernel, dim3((unsigned)(n * L)), dim3(512), 0, stream,
+                     (const float*)(m->prep + cnf::hdr_floats(5)), m->per_layer, c, 0.0f, L, sp_offset, *tables);
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 

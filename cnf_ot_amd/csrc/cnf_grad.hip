@@ -14,6 +14,8 @@
 //     the result is deterministic); grad_finish_kernel sums the slabs.
 // Built for the reference's network only: hidden 16, 2 hidden layers, 5 bins.
 #include "cnf_backward.h"
+#define CNF_PWL_NO_BUILDER
+#include "cnf_pwl.h"
 
 #include <math.h>
 
@@ -572,6 +574,352 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void vjp_kernel(const 
   }
 }
 
+// ---------------------------------------------------------------------------
+// The backward of ONE flow pass at dim 2 on the conditioner tables (cnf_pwl.h), with PER-PIECE SUFFICIENT
+// STATISTICS in place of per-sample weight gradients.  On a piece of a slice's table both ReLU activity patterns
+// are constant and theta, h2, h1 are affine in the conditioner's scalar input u, so every weight gradient is linear
+// in  A = sum theta_bar  and  B = sum (u - u_ref) theta_bar  over the samples that land in the piece
+// (oracle/pwl_grad.py restates the algebra; checked against per-sample backprop to 1e-9).  Per sample that leaves:
+// the forward through the tables, the spline partials (cond_spline_bwd / table_spline_bwd as in the MLP kernels),
+// the input adjoint S . theta_bar from the row already in LDS, and 24 accumulations -- no MLP recompute and no
+// per-sample GEMM.  pwl_stats_finish_kernel turns the statistics into gradient slabs, once per piece.
+//   vjp_pwl_kernel: one sample per lane, 1024 threads; LDS = `first` table | L tables (PWL_LROWS-row window) |
+//   64-bit fixed-point accumulators [L][64 pieces][33] (A | B per piece).
+// ---------------------------------------------------------------------------
+constexpr int PWL_STAT = 2 * PWL_P;                 // statistics per piece: A[16] | B[16]
+// The statistics are accumulated in 64-bit FIXED POINT: measured on MI355X, ds_add_f32 retires a lane every ~2.6
+// cycles whatever the addresses (the accumulation was 0.9 of 1.2 ms per 4.2 M-point pass, and neither bank padding
+// nor replicated accumulators changed it), integer LDS atomics are ~15 x faster -- and integer sums do not depend
+// on the order of the additions, so the gradient is bitwise reproducible like the slab scheme of the MLP kernels.
+// Scale: 2^s with s = 28 - exponent of the largest |ybar|, |ldbar| of the call (adjoint_max_kernel): resolution
+// 2^-28 of that magnitude (float32 itself resolves 2^-24), a single term may be 2^23 x it (the 1.5 2^52 rounding trick
+// holds below 2^51), a sum 2^35 x it.
+// In LDS a piece's 32 accumulators are 33 entries apart (entry m of piece p in bank pair (p + m) mod 32: lanes of
+// different pieces do not collide); only the first PWL_ACC_W pieces have LDS accumulators (the rest -- far pieces,
+// few samples -- go to global memory).
+typedef unsigned long long stat_t;
+constexpr int PWL_STAT_LDS = PWL_STAT + 1;
+constexpr int PWL_ACC_W = 64;
+constexpr int PWL_STAT_SLICES = 64;                 // slices per chunk of the table backward (statistics buffer)
+
+// 2^(28 - e) for the largest adjoint magnitude 2^e <= |x| < 2^(e+1) (bits of |x| as given by adjoint_max_kernel);
+// all-zero adjoints: any scale will do
+__device__ __forceinline__ double stat_scale(uint32_t amax_bits) {
+  int e = (int)(amax_bits >> 23) - 127;
+  if (amax_bits == 0) e = 0;
+  if (e < -100) e = -100;
+  return __longlong_as_double((long long)(1023 + 28 - e) << 52);
+}
+
+// the largest |ybar|, |ldbar| of a call (bit pattern of a non-negative float: ordered like the integers)
+__global__ void adjoint_max_kernel(const float* __restrict__ ybar, int64_t n_y, const float* __restrict__ ldbar,
+                                   int64_t n_l, uint32_t* out) {
+  uint32_t m = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_y; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t b = __float_as_uint(ybar[i]) & 0x7fffffffu;
+    m = b > m && b < 0x7f800000u ? b : m;
+  }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_l; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t b = __float_as_uint(ldbar[i]) & 0x7fffffffu;
+    m = b > m && b < 0x7f800000u ? b : m;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+struct VjpPwlArgs {
+  ModelArgs m;
+  const float* pts;      // [B, 2] inputs of the pass
+  const float* ybar;     // [B, 2] or null
+  const float* ldbar;    // [B] or null
+  float* xbar;           // [B, 2] or null
+  const float* tables;   // [n_slices][L][PWL_TBL]
+  stat_t* stats;         // [n_slices][L][PWL_NPIECE][PWL_STAT] fixed point, zero on entry
+  const uint32_t* amax;  // bits of the largest |adjoint| of the call (adjoint_max_kernel)
+  float* first_acc;      // [GP] per-bin adjoint sums of the `first` spline (a slab's first entries), zero on entry
+  int64_t B, slice_len;
+  int32_t n_slices, tiles_per_slice;
+};
+
+template <bool TO_BASE>
+__global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
+  constexpr int K = GK, WIN = PWL_LROWS;
+  constexpr bool INV = !TO_BASE;
+  constexpr int MAXL = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  constexpr int HDR = (hdr_floats(K) + 3) & ~3;
+  const int L = a.m.L, NT = blockDim.x, tid = threadIdx.x;
+  float* tab = lds_raw;
+  float* tbl = lds_raw + HDR;
+  stat_t* acc = reinterpret_cast<stat_t*>(tbl + L * pwl_ltbl(WIN));      // [L][PWL_ACC_W][PWL_STAT_LDS] (8-byte aligned: HDR, pwl_ltbl even)
+  float* red = reinterpret_cast<float*>(acc + L * PWL_ACC_W * PWL_STAT_LDS);      // [waves][GP]
+  for (int i = tid; i < hdr_floats(K); i += NT) tab[i] = a.m.prep[i];
+  for (int i = tid; i < L * PWL_ACC_W * PWL_STAT_LDS; i += NT) acc[i] = 0;
+  const SplineConsts sc = sc_scalars(a.m.sc);
+  // fixed-point scale 2^(28 - e), e = the exponent of the largest adjoint; x -> round(x scale) by the 1.5 2^52 trick
+  const double fx_scale = stat_scale(*a.amax);
+  auto to_fixed = [&](float x) -> stat_t {
+    const double d = fma((double)x, fx_scale, 6755399441055744.0);
+    return (stat_t)(__double_as_longlong(d) - __double_as_longlong(6755399441055744.0));
+  };
+  FirstAcc fa;
+#pragma unroll
+  for (int j = 0; j < GK; ++j) { fa.Wb[j] = 0.0f; fa.Hb[j] = 0.0f; }
+#pragma unroll
+  for (int j = 0; j <= GK; ++j) fa.Db[j] = 0.0f;
+
+  auto flush = [&](int slice) {          // LDS accumulators -> the slice's statistics, and clear
+    __syncthreads();
+    stat_t* g = a.stats + (int64_t)slice * L * PWL_NPIECE * PWL_STAT;
+    for (int i = tid; i < L * PWL_ACC_W * PWL_STAT; i += NT) {
+      const int lp = i / PWL_STAT, m2 = i - lp * PWL_STAT;            // (layer, piece), entry
+      const int l = lp / PWL_ACC_W, p = lp - l * PWL_ACC_W;
+      stat_t* e = acc + lp * PWL_STAT_LDS + m2;
+      const stat_t v = *e;
+      if (v != 0) { atomicAdd(g + ((int64_t)l * PWL_NPIECE + p) * PWL_STAT + m2, v); *e = 0; }
+    }
+    __syncthreads();
+  };
+
+  const int total = a.n_slices * a.tiles_per_slice;
+  const int per_block = (total + gridDim.x - 1) / gridDim.x;
+  const int t0 = blockIdx.x * per_block;
+  const int t1 = t0 + per_block < total ? t0 + per_block : total;
+  int cur = -1;
+  for (int tile = t0; tile < t1; ++tile) {
+    const int slice = tile / a.tiles_per_slice;
+    if (slice != cur) {
+      if (cur >= 0) flush(cur); else __syncthreads();
+      pwl_stage<WIN>(tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, tid, NT);
+      cur = slice;
+      __syncthreads();
+    }
+    const int64_t s0 = (int64_t)slice * a.slice_len;
+    const int64_t len = a.B - s0 < a.slice_len ? a.B - s0 : a.slice_len;
+    const int64_t j = (int64_t)(tile - slice * a.tiles_per_slice) * NT + tid;
+    const int64_t g = s0 + j;
+    const bool valid = j < len;
+    float u[2] = {0.0f, 0.0f}, ob[2] = {0.0f, 0.0f};
+    float ld_bar = 0.0f;
+    if (valid) {
+      const v2f x = *reinterpret_cast<const v2f*>(a.pts + 2 * g);
+      u[0] = x.x; u[1] = x.y;
+      if (a.ybar) { const v2f y = *reinterpret_cast<const v2f*>(a.ybar + 2 * g); ob[0] = y.x; ob[1] = y.y; }
+      if (a.ldbar) ld_bar = a.ldbar[g];
+    }
+    const float* gtbl = a.tables + (int64_t)slice * L * PWL_TBL;
+    // ---- forward through the tables, keeping every layer's inputs and outputs
+    float in_f[MAXL], in_o[MAXL], out_f[MAXL], out_o[MAXL];
+#pragma unroll
+    for (int step = 0; step < MAXL; ++step) {
+      if (step < L) {
+        const int l = TO_BASE ? L - 1 - step : step;
+        const bool odd = l & 1;
+        const float uf = odd ? u[1] : u[0], uo = odd ? u[0] : u[1];
+        float of, oo, ld;
+        table_spline<K, INV, true, float>(tab, uf, sc, of, ld);
+        float th[PWL_P];
+        bool general;
+        pwl_eval<WIN>(tbl + l * pwl_ltbl(WIN), gtbl + (int64_t)l * PWL_TBL, TO_BASE ? of : uf, th, general);
+#pragma unroll
+        for (int m2 = 0; m2 < 2 * K; ++m2) th[m2] *= LN2;                        // table rows: log2 units ...
+#pragma unroll
+        for (int m2 = 2 * K; m2 < PWL_P; ++m2) th[m2] = fmaf(th[m2], LN2, -sc.sp_offset);   // ... slopes with the offset added
+        cond_spline<K, INV, true, float>(th, uo, sc, oo, ld);
+        in_f[step] = uf; in_o[step] = uo; out_f[step] = of; out_o[step] = oo;
+        u[odd ? 1 : 0] = of; u[odd ? 0 : 1] = oo;
+      }
+    }
+    // ---- backward
+#pragma unroll
+    for (int step = MAXL - 1; step >= 0; --step) {
+      if (step < L) {
+        const int l = TO_BASE ? L - 1 - step : step;
+        const bool odd = l & 1;
+        float ob_f = odd ? ob[1] : ob[0];
+        const float ob_o = odd ? ob[0] : ob[1];
+        const float* tl = tbl + l * pwl_ltbl(WIN);
+        const float* gl = gtbl + (int64_t)l * PWL_TBL;
+        const float ucond = TO_BASE ? out_f[step] : in_f[step];
+        bool general;
+        const int p = pwl_piece(tl, ucond, general);
+        const float du = ucond - tl[PWL_OFF_REF + p];
+        // the piece's slopes S and intercepts: theta (natural units) and d theta / d u
+        float S[PWL_P], th[PWL_P];
+        {
+          const float* row = p < WIN ? tl + PWL_OFF_PIECE + p * PWL_ROW : gl + PWL_OFF_PIECE + p * PWL_ROW;
+#pragma unroll
+          for (int m2 = 0; m2 < PWL_P; ++m2) {
+            S[m2] = row[m2] * LN2;
+            th[m2] = fmaf(row[m2], du, row[PWL_P + m2]) * LN2 - (m2 >= 2 * K ? sc.sp_offset : 0.0f);
+          }
+        }
+        float tb[PWL_P];
+        const float ub_o = cond_spline_bwd<K, INV, true>(th, in_o[step], out_o[step], ob_o, ld_bar, sc, tb);
+        float ucond_bar = 0.0f;
+#pragma unroll
+        for (int m2 = 0; m2 < PWL_P; ++m2) ucond_bar = fmaf(S[m2], tb[m2], ucond_bar);
+#ifndef CNF_VJP_PWL_NO_ATOMICS     /* experiment switch: what the accumulation costs */
+        if (valid) {
+          stat_t* dst = p < PWL_ACC_W ? acc + (l * PWL_ACC_W + p) * PWL_STAT_LDS
+                                      : a.stats + (((int64_t)slice * L + l) * PWL_NPIECE + p) * PWL_STAT;
+#pragma unroll
+          for (int m2 = 0; m2 < PWL_P; ++m2) {
+            if (tb[m2] != 0.0f) {
+              const stat_t qa = to_fixed(tb[m2]), qb = to_fixed(du * tb[m2]);
+              if (p < PWL_ACC_W) {          // LDS: ds_add_u64
+                typedef stat_t __attribute__((address_space(3))) * lds_q_ptr;
+                lds_q_ptr d3 = (lds_q_ptr)(uintptr_t)(uint32_t)(uintptr_t)dst;
+                __hip_atomic_fetch_add(d3 + m2, qa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(d3 + PWL_P + m2, qb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              } else {                      // a piece without LDS accumulators: straight to the slice's statistics
+                atomicAdd(dst + m2, qa); atomicAdd(dst + PWL_P + m2, qb);
+              }
+            }
+          }
+        }
+#endif
+        float ub_f = 0.0f;
+        if (TO_BASE) ob_f += ucond_bar; else ub_f = ucond_bar;
+        ub_f += table_spline_bwd<K, INV>(tab, in_f[step], out_f[step], ob_f, ld_bar, sc, fa.Wb, fa.Hb, fa.Db);
+        ob[odd ? 1 : 0] = ub_f; ob[odd ? 0 : 1] = ub_o;
+      }
+    }
+    if (a.xbar && valid) *reinterpret_cast<v2f*>(a.xbar + 2 * g) = v2f{ob[0], ob[1]};
+  }
+  if (cur >= 0) flush(cur);
+  // the `first` spline's per-bin adjoint sums: wave shuffle, block reduce, one atomic per entry and block
+  {
+    float r[GP];
+#pragma unroll
+    for (int j = 0; j < GK; ++j) { r[j] = fa.Wb[j]; r[GK + j] = fa.Hb[j]; }
+#pragma unroll
+    for (int j = 0; j <= GK; ++j) r[2 * GK + j] = fa.Db[j];
+#pragma unroll
+    for (int j = 0; j < GP; ++j) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) r[j] += __shfl_xor(r[j], off, 64);
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int j = 0; j < GP; ++j) red[(tid >> 6) * GP + j] = r[j];
+    }
+    __syncthreads();
+    if (tid < GP) {
+      float s = 0.0f;
+      for (int w2 = 0; w2 < (NT >> 6); ++w2) s += red[w2 * GP + tid];
+      unsafeAtomicAdd(a.first_acc + tid, s);
+    }
+  }
+}
+
+// One block per (slice, layer): the slice's per-piece statistics -> that layer's 592 conditioner gradients, written
+// (with zeros elsewhere) into slab 1 + block; the statistics are cleared for the next call.
+struct StatsFinishArgs {
+  const float* weights;  // prep + hdr: the conditioner weights snapshot
+  int64_t per_layer;
+  const float* cvals;    // [n_slices]
+  const float* tables;
+  stat_t* stats;
+  const uint32_t* amax;
+  float* slabs;          // [1 + n_slices * L][n_params]
+  int64_t n_params;
+  int32_t L;
+};
+
+__global__ __launch_bounds__(256) void pwl_stats_finish_kernel(const StatsFinishArgs a) {
+  constexpr int H = PWL_H, P = PWL_P, NW = 2 * H + H + H * H + H + H * P + P;      // 592 floats of one conditioner
+  constexpr int NWV = 4;                                   // waves: one piece per wave at a time
+  constexpr int PER_LANE = (NW + 63) / 64;                 // 10 outputs per lane
+  __shared__ float av[H], bv[H], W1[H * H], b1[H], Wo[H * P];
+  __shared__ float stat[PWL_NPIECE * PWL_STAT];            // the slice-layer's statistics, read once (37 KB)
+  __shared__ float scr[NWV][9 * H];                        // per wave: Bu | m1a | m1b | Pk | Qk | G2 | G2u | G1 | G1u
+  __shared__ float part[NWV][NW];                          // the waves' partial results
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int slice = blockIdx.x / a.L, l = blockIdx.x % a.L;
+  const float* w = a.weights + l * a.per_layer;
+  const float c = a.cvals[slice];
+  if (tid < H) {
+    av[tid] = w[H + tid];
+    bv[tid] = fmaf(w[tid], c, w[2 * H + tid]);
+    b1[tid] = w[3 * H + H * H + tid];
+  }
+  for (int i = tid; i < H * H; i += blockDim.x) { W1[i] = w[3 * H + i]; Wo[i] = w[3 * H + H * H + H + i]; }
+  const float* T = a.tables + (int64_t)blockIdx.x * PWL_TBL;
+  stat_t* st = a.stats + (int64_t)blockIdx.x * PWL_NPIECE * PWL_STAT;
+  const int n = __float_as_int(T[PWL_N_SLOT]);
+  const double inv_scale = 1.0 / stat_scale(*a.amax);
+  for (int i = tid; i < (n + 1) * PWL_STAT; i += blockDim.x) {
+    const stat_t q = st[i];
+    stat[i] = (float)((double)(long long)q * inv_scale);
+    if (q != 0) st[i] = 0;                                 // cleared for the next call
+  }
+  __syncthreads();
+  float out[PER_LANE];
+#pragma unroll
+  for (int q = 0; q < PER_LANE; ++q) out[q] = 0.0f;
+  float* Bu = scr[wv], *m1a = Bu + H, *m1b = m1a + H, *Pk = m1b + H, *Qk = Pk + H, *G2 = Qk + H, *G2u = G2 + H,
+        *G1 = G2u + H, *G1u = G1 + H;
+  for (int p = wv; p <= n; p += NWV) {                     // wave-uniform loop: no block barrier inside
+    const float* A = stat + p * PWL_STAT;
+    const float sv = lane < PWL_STAT ? A[lane] : 0.0f;
+    if (__builtin_amdgcn_ballot_w64(sv != 0.0f) == 0) continue;
+    const float lo = p == 0 ? -INFINITY : T[p - 1], hi = p < n ? T[p] : INFINITY;
+    const bool fl = lo > -INFINITY, fh = hi < INFINITY;
+    const float ut = fl && fh ? 0.5f * (lo + hi) : (fl ? lo + 1.0f : (fh ? hi - 1.0f : 0.0f));
+    const float uref = T[PWL_OFF_REF + p];
+    float on1 = 0.0f;
+    if (lane < H) {
+      Bu[lane] = fmaf(uref, A[lane], A[P + lane]);          // sum (u - u_ref) g  ->  sum u g
+      on1 = fmaf(av[lane], ut, bv[lane]) > 0.0f ? 1.0f : 0.0f;
+      m1a[lane] = on1 * av[lane]; m1b[lane] = on1 * bv[lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (lane < H) {
+      const int k = lane;
+      float Ps = 0.0f, Qs = b1[k], ha = 0.0f, hb = 0.0f;
+      for (int j = 0; j < H; ++j) { Ps = fmaf(W1[j * H + k], m1a[j], Ps); Qs = fmaf(W1[j * H + k], m1b[j], Qs); }
+      for (int m = 0; m < P; ++m) { ha = fmaf(Wo[k * P + m], A[m], ha); hb = fmaf(Wo[k * P + m], Bu[m], hb); }
+      const float on2 = fmaf(Ps, ut, Qs) > 0.0f ? 1.0f : 0.0f;
+      Pk[k] = on2 * Ps; Qk[k] = on2 * Qs; G2[k] = on2 * ha; G2u[k] = on2 * hb;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (lane < H) {
+      float ga = 0.0f, gb = 0.0f;
+      for (int k = 0; k < H; ++k) { ga = fmaf(W1[lane * H + k], G2[k], ga); gb = fmaf(W1[lane * H + k], G2u[k], gb); }
+      G1[lane] = on1 * ga; G1u[lane] = on1 * gb;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < PER_LANE; ++q) {
+      const int o = lane + q * 64;
+      if (o < NW) {
+        float v;
+        if (o < H) v = c * G1[o];                                            // W0[c row]
+        else if (o < 2 * H) v = G1u[o - H];                                  // W0[u row]
+        else if (o < 3 * H) v = G1[o - 2 * H];                               // b0
+        else if (o < 3 * H + H * H) { const int e = o - 3 * H, j = e / H, k = e % H; v = fmaf(m1a[j], G2u[k], m1b[j] * G2[k]); }
+        else if (o < 4 * H + H * H) v = G2[o - 3 * H - H * H];               // b1
+        else if (o < 4 * H + H * H + H * P) { const int e = o - 4 * H - H * H, k = e / P, m = e % P; v = fmaf(Pk[k], Bu[m], Qk[k] * A[m]); }
+        else v = A[o - 4 * H - H * H - H * P];                               // bo
+        out[q] += v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();      // scr is reused by the next piece
+  }
+#pragma unroll
+  for (int q = 0; q < PER_LANE; ++q) { const int o = lane + q * 64; if (o < NW) part[wv][o] = out[q]; }
+  __syncthreads();
+  // slab 1 + block: zeros except this layer's conditioner
+  float* slab = a.slabs + (int64_t)(1 + blockIdx.x) * a.n_params;
+  const int64_t base = GP + (int64_t)l * a.per_layer;
+  for (int64_t i = tid; i < a.n_params; i += blockDim.x) {
+    const int64_t o = i - base;
+    slab[i] = (o >= 0 && o < NW) ? (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]) : 0.0f;
+  }
+}
+
 // grad[p] += sum over slabs; the first 16 entries are per-bin adjoint sums of
 // the `first` spline and go through the softmax / softplus Jacobians (float64).
 // Block = 32 parameters x 32 slab stripes (a thread that walks all slabs alone
@@ -841,6 +1189,17 @@ extern "C" int cnf_grad_enable(CnfModel* m, int64_t max_blocks) {
   if (m->grad_slabs) { (void)hipFree(m->grad_slabs); m->grad_slabs = nullptr; }
   if (hipMalloc((void**)&m->grad_slabs, sizeof(float) * (size_t)(max_blocks * 4 * m->n_params)) != hipSuccess) return CNF_ERR_NOMEM;
   m->grad_max_blocks = max_blocks;
+  // the table backward of dim-2 passes (vjp_pwl_kernel): per-piece statistics of PWL_STAT_SLICES slices, kept zero
+  // between calls (pwl_stats_finish_kernel clears what it reads)
+  if (!m->pwl_stats && m->cfg.dim == 2 && m->cfg.num_layers <= 4 && m->cfg.mlp_num_layers == 2) {
+    // [64 bytes: the call's largest adjoint][statistics]
+    const size_t bytes = 64 + sizeof(stat_t) * (size_t)PWL_STAT_SLICES * m->cfg.num_layers * PWL_NPIECE * PWL_STAT;
+    if (hipMalloc((void**)&m->pwl_stats, bytes) == hipSuccess) {
+      if (hipMemset(m->pwl_stats, 0, bytes) != hipSuccess) { (void)hipFree(m->pwl_stats); m->pwl_stats = nullptr; }
+    } else {
+      m->pwl_stats = nullptr;          // (the MLP backward remains)
+    }
+  }
   return CNF_OK;
 }
 
@@ -854,6 +1213,69 @@ extern "C" int cnf_adam_step(float* params, const float* grad, float* mu, float*
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 
+// The table form of cnf_pass_vjp (vjp_pwl_kernel + pwl_stats_finish_kernel + grad_finish_kernel): dim 2, the
+// reference's network, a condition uniform over slices, tables reserved on the stream (cnf_model_reserve) for at
+// least min(n_slices, PWL_STAT_SLICES) slices.  CNF_ERR_UNSUPPORTED: the caller runs the MLP backward.
+static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float* c, int64_t c_block,
+                        const float* ybar, const float* ldbar, float* xbar, float* grad, const float* params,
+                        int64_t B, hipStream_t stream) {
+  const CnfConfig& g = m->cfg;
+  if (!m->use_pwl || !m->fast_math || !m->pwl_stats || g.dim != 2 || g.hidden_size != PWL_H || g.num_bins != GK ||
+      g.mlp_num_layers != 2 || g.num_layers > 4 || g.periodized)
+    return CNF_ERR_UNSUPPORTED;
+  const int L = g.num_layers;
+  const int64_t slice_len = c_block < B ? c_block : B;
+  const int64_t n_slices = (B + slice_len - 1) / slice_len;
+  // worth it while a slice amortises its tables and their per-piece finishing (measured crossover: see DESIGN.md)
+  // (measured, scripts/exp_vjp_tables.py: 4.2 M points 0.46 vs 0.94 ms for the MLP backward, 131 072 points 0.085 vs
+  // 0.050 ms: ~0.06 ms of fixed cost -- table build, adjoint maximum, per-piece finishing -- against 0.12 us saved per
+  // 1 000 points)
+  if (m->use_pwl == 1 && (slice_len < 8192 || B < 524288)) return CNF_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(pts) & 7) || (reinterpret_cast<uintptr_t>(ybar) & 7) ||
+      (reinterpret_cast<uintptr_t>(xbar) & 7) || (n_slices > 1 && (slice_len & 1)))
+    return CNF_ERR_UNSUPPORTED;
+  const int threads = 1024;
+  const size_t lds = sizeof(float) * (size_t)(((hdr_floats(GK) + 3) & ~3) + L * pwl_ltbl(PWL_LROWS) +
+                                              2 * L * PWL_ACC_W * PWL_STAT_LDS + (threads / 64) * GP);
+  if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
+  if (to_base ? !ensure_lds(vjp_pwl_kernel<true>, lds) : !ensure_lds(vjp_pwl_kernel<false>, lds)) return CNF_ERR_UNSUPPORTED;
+  const int64_t tps = (slice_len + threads - 1) / threads;
+  for (int64_t s0 = 0; s0 < n_slices; s0 += PWL_STAT_SLICES) {
+    const int64_t ns = n_slices - s0 < PWL_STAT_SLICES ? n_slices - s0 : PWL_STAT_SLICES;
+    float* tables = nullptr;
+    const int r = cnf_internal_build_tables(m, stream, c + s0, ns, &tables);
+    if (r != CNF_OK) return s0 == 0 ? r : CNF_ERR_HIP;          // (a later chunk cannot fail on its own)
+    m->last_path = CNF_PATH_TABLES;
+    if (hipMemsetAsync(m->grad_slabs, 0, sizeof(float) * (size_t)m->n_params, stream) != hipSuccess) return CNF_ERR_HIP;
+    const int64_t first = s0 * slice_len;
+    VjpPwlArgs a;
+    a.m = model_args(m);
+    a.pts = pts + 2 * first; a.ybar = ybar ? ybar + 2 * first : nullptr; a.ldbar = ldbar ? ldbar + first : nullptr;
+    a.xbar = xbar ? xbar + 2 * first : nullptr;
+    uint32_t* amax = reinterpret_cast<uint32_t*>(m->pwl_stats);
+    stat_t* stats = reinterpret_cast<stat_t*>(reinterpret_cast<char*>(m->pwl_stats) + 64);
+    a.tables = tables; a.stats = stats; a.amax = amax; a.first_acc = m->grad_slabs;
+    a.B = (B - first) < ns * slice_len ? (B - first) : ns * slice_len;
+    a.slice_len = slice_len; a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps;
+    if (hipMemsetAsync(amax, 0, 4, stream) != hipSuccess) return CNF_ERR_HIP;
+    hipLaunchKernelGGL(adjoint_max_kernel, dim3(256), dim3(256), 0, stream, a.ybar, a.ybar ? 2 * a.B : 0, a.ldbar,
+                       a.ldbar ? a.B : 0, amax);
+    const int64_t tiles = ns * tps;
+    const int64_t grid = tiles < m->num_cus ? tiles : m->num_cus;
+    if (to_base) hipLaunchKernelGGL(vjp_pwl_kernel<true>, dim3((unsigned)grid), dim3(threads), lds, stream, a);
+    else hipLaunchKernelGGL(vjp_pwl_kernel<false>, dim3((unsigned)grid), dim3(threads), lds, stream, a);
+    StatsFinishArgs f;
+    f.weights = m->prep + hdr_floats(GK); f.per_layer = m->per_layer; f.cvals = c + s0; f.tables = tables;
+    f.stats = stats; f.amax = amax; f.slabs = m->grad_slabs; f.n_params = m->n_params; f.L = L;
+    hipLaunchKernelGGL(pwl_stats_finish_kernel, dim3((unsigned)(ns * L)), dim3(256), 0, stream, f);
+    const int fb = (int)((m->n_params + 31) / 32);
+    hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, 1 + ns * L, m->n_params,
+                       params, grad, (double)m->sc.span_eff, (double)m->sc.sp_offset);
+    if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
+  }
+  return CNF_OK;
+}
+
 static int pass_vjp_impl(CnfModel* m, int to_base, const float* pts, const float* c, int64_t c_block,
                          const float* ybar, const float* ldbar, float* xbar, float* grad, const float* params,
                          int64_t B, void* stream_) {
@@ -865,6 +1287,10 @@ static int pass_vjp_impl(CnfModel* m, int to_base, const float* pts, const float
   if (grad && !m->grad_slabs) return CNF_ERR_INVALID;      // cnf_grad_enable first
   hipStream_t stream = (hipStream_t)stream_;
   if (wait_for_params(m, stream) != CNF_OK) return CNF_ERR_HIP;
+  if (grad) {
+    const int r = pass_vjp_pwl(m, to_base, pts, c, c_block, ybar, ldbar, xbar, grad, params, B, stream);
+    if (r != CNF_ERR_UNSUPPORTED) return r;
+  }
   VjpArgs a;
   a.m = model_args(m); a.pts = pts; a.c = c; a.ybar = ybar; a.ldbar = ldbar; a.xbar = xbar;
   a.slabs = m->grad_slabs; a.n_params = m->n_params;

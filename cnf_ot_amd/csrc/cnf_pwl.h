@@ -77,6 +77,7 @@ constexpr double PWL_FAST_SLOPE_LO = -3.0;       // below: log(1 + e^v) in fp32 
 constexpr double PWL_FAST_SLOPE_HI = 40.0;
 constexpr int PWL_CHUNK = 64;             // pieces per pass of the two-stage affine-map computation
 
+#ifndef CNF_PWL_NO_BUILDER          /* (a second translation unit that only READS tables defines this) */
 __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict__ weights /* prep + hdr */,
                                                         int64_t per_layer, const float* __restrict__ cvals,
                                                         float c_offset, int L, double sp_offset,
@@ -322,6 +323,8 @@ __global__ __launch_bounds__(512) void pwl_build_kernel(const float* __restrict_
   }
 }
 
+#endif  // CNF_PWL_NO_BUILDER
+
 // The compiler would pair the two samples' FMAs into v_pk_fma_f32 and pay ~40 v_mov to interleave
 // the two gathered rows; a plain v_fma_f32 per half needs none.
 __device__ __forceinline__ float fma_scalar(float a, float b, float c) {
@@ -485,6 +488,19 @@ __device__ __forceinline__ v2f pwl_slope_pair(lds_f_ptr row, const float* __rest
     t = __builtin_elementwise_fma(v2f{g[10], g[11]}, d2, v2f{g[PWL_P + 10], g[PWL_P + 11]});
   }
   return t;
+}
+
+// Stage the L tables of (set, slice) into LDS: header arrays + the rows in use, at most LROWS.
+template <int LROWS = PWL_LROWS>
+__device__ __forceinline__ void pwl_stage(float* tbl, const float* __restrict__ g0, int L, int tid, int nthreads) {
+  for (int l = 0; l < L; ++l) {
+    const float* g = g0 + (int64_t)l * PWL_TBL;
+    const int n = __float_as_int(g[PWL_N_SLOT]);                       // pieces 0 .. n
+    const int rows = n + 1 < LROWS ? n + 1 : LROWS;
+    const f4* src = reinterpret_cast<const f4*>(g);
+    f4* dst = reinterpret_cast<f4*>(tbl + l * pwl_ltbl(LROWS));
+    for (int i = tid; i < (PWL_OFF_PIECE + rows * PWL_ROW) / 4; i += nthreads) dst[i] = src[i];
+  }
 }
 
 }  // namespace cnf

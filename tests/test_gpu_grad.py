@@ -317,3 +317,41 @@ def test_logprob_fd_score_and_its_backward(dev, D, B):
     rel_x = (rr.grad - rr2.grad).abs().max().item() / rr2.grad.abs().max().item()
     print(f"\n[logprob_fd D={D} per_sample_c={per}] param-grad rel {rel_p:.2e}  point-adjoint rel {rel_x:.2e}")
     assert rel_p <= 1e-4 and rel_x <= 1e-4
+
+
+@pytest.mark.parametrize("to_base", [False, True])
+def test_pass_vjp_table_form_matches_mlp_backward(dev, to_base):
+  """cnf_pass_vjp at dim 2 on the conditioner tables: per-piece sufficient statistics (A = sum theta_bar,
+  B = sum (u - u_ref) theta_bar) instead of per-sample weight gradients (algebra restated and checked
+  on the CPU in oracle/pwl_grad.py).  Same input adjoints and the same parameter gradient as the MLP backward, on
+  slices of ragged length with a partial last slice."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  cfg = FlowConfig(dim=2)
+  params = Params.random(cfg, 0.2, seed=5, device=dev)
+  eng = FlowEngine(cfg, dev).load(params)
+  gen = torch.Generator(device="cpu").manual_seed(3)
+  S, Bs = 5, 6002                          # slices of 5 full tiles of 1 024 + a partial one
+  B = S * Bs
+  pts = torch.randn(B, 2, generator=gen).to(dev) * (1.0 if not to_base else 1.5)
+  ts = torch.linspace(0.1, 0.9, S).to(dev)
+  ybar = torch.randn(B, 2, generator=gen).to(dev)
+  ldbar = torch.randn(B, generator=gen).to(dev)
+  c_host = ts.repeat_interleave(Bs)[:B].contiguous()
+  res = {}
+  for mode in (0, 2):
+    eng.set_pwl(mode)
+    g = torch.zeros(cfg.param_count(), device=dev)
+    # mode 0: per-sample conditions (the MLP backward); mode 2: the slices' conditions, c_block = Bs
+    xbar = eng.pass_vjp(pts, ts if mode == 2 else c_host[:, None], ybar, ldbar, to_base, grad=g)
+    torch.cuda.synchronize()
+    res[mode] = (xbar, g, eng.last_path())
+  assert res[2][2] == "tables" and res[0][2] != "tables"
+  xb0, g0, _ = res[0]; xb2, g2, _ = res[2]
+  ex = (xb2 - xb0).abs().max().item() / xb0.abs().max().item()
+  eg = (g2 - g0).abs().max().item() / g0.abs().max().item()
+  print(f"\n[pass_vjp tables vs mlp, to_base={to_base}] xbar rel {ex:.2e}  grad rel {eg:.2e}  |g|inf {g0.abs().max().item():.3g}")
+  assert ex <= 2e-5 and eg <= 5e-5
+  # the `first` block and every tensor of a conditioner individually (a wrong row would hide in the maximum)
+  for lo, hi in ((0, 16), (16, 48), (48, 64), (64, 320), (320, 336), (336, 592), (592, 608), (608, 1200)):
+    ref = g0[lo:hi].abs().max().item()
+    assert (g2[lo:hi] - g0[lo:hi]).abs().max().item() <= 1e-4 * max(ref, 1e-3 * g0.abs().max().item()), (lo, hi)
