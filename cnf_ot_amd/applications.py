@@ -129,6 +129,75 @@ def _source_samples(ctx, z, start, count, n_global, source):
   raise ValueError(f"unknown source {source!r}")
 
 
+# ---- dim 2, value_and_grad of large batches: the terms composed from table-path launches ---------------------------
+# The fused gradient kernel evaluates the conditioner MLP per sample and multiplies per-sample weight gradients on
+# the matrix cores (4 G flow passes/s); cnf_pass_vjp on the conditioner tables needs neither (per-piece sufficient
+# statistics: DESIGN.md 5.4, 9 G passes/s).  So when a rank's share of a term is large enough for the tables
+# (cnf_grad.hip: slices >= 8 192 points, >= 524 288 points per pass) the term is ONE forward launch on the tables,
+# a few elementwise kernels for its value and adjoints, and ONE table backward launch.
+TABLE_BACKWARD_MIN_SLICE = 8192
+TABLE_BACKWARD_MIN_POINTS = 524288
+
+
+def _use_table_backward(ctx, dim, count, n_slices, passes=1):
+  be = ctx.be
+  return (ctx.grad is not None and dim == 2 and hasattr(be, "pass_vjp") and getattr(be, "_tables_ok", False)
+          and getattr(be, "_pwl_mode", 0) != 0 and count >= TABLE_BACKWARD_MIN_SLICE
+          and count * n_slices * passes >= TABLE_BACKWARD_MIN_POINTS)
+
+
+def _neg_logprob_tables(ctx, samples, cond, coef):
+  """-sum log_prob(samples; cond) and its gradient: data -> base pass, log_prob = base(x) + ildj."""
+  be = ctx.be
+  c = be.slice_conds([cond])
+  x, ildj = be.inverse_logdet(samples, c)
+  lp = ildj.double() - 0.5 * (x.double() ** 2).sum(1) - np.log(2.0 * np.pi)
+  # d(-sum lp) scaled by coef: lp_bar = -coef; x_bar = lp_bar * d base/dx = coef * x; ld_bar = -coef
+  be.pass_vjp(samples, c, x * float(coef), torch.full_like(ildj, -float(coef)), True, grad=ctx.grad, want_xbar=False)
+  return -lp.sum().reshape(1)
+
+
+def _kinetic_tables(ctx, z, conds, count, dt, coef):
+  """per-slice sums of |(r2 - r1) / dt|^2 with r1, r2 the same draw pushed to t -+ dt/2 (applications.py:220-242)."""
+  be = ctx.be
+  th = np.asarray(conds, dtype=np.float32).reshape(-1)
+  S = th.size
+  half = np.float32(0.5 * dt)
+  c2 = be.slice_conds(np.concatenate([th - half, th + half]))
+  z2 = z.repeat(2 * S, 1)
+  r, _ = be.forward_logdet(z2, c2, want_logdet=False)
+  n = S * count
+  v = (r[n:] - r[:n]) * (1.0 / dt)
+  sums = (v.double() ** 2).view(S, -1).sum(1)
+  g = v * (2.0 * float(coef) / dt)                         # d(coef * sum v^2) / d r2 = -d / d r1
+  be.pass_vjp(z2, c2, torch.cat([-g, g]), None, False, grad=ctx.grad, want_xbar=False)
+  return sums
+
+
+def _potential_tables(ctx, z, conds, count, subtype, a, coef):
+  """per-slice sums of the potential at the samples pushed to the slices' times (applications.py:176-205)."""
+  be = ctx.be
+  th = np.asarray(conds, dtype=np.float32).reshape(-1)
+  S = th.size
+  c = be.slice_conds(th)
+  zr = z.repeat(S, 1) if S > 1 else z
+  r, _ = be.forward_logdet(zr, c, want_logdet=False)
+  s2 = (r * r).sum(1)
+  if subtype == "quadratic":                               # |r|^2 / 2
+    val, rbar = 0.5 * s2, r * float(coef)
+  elif subtype == "obstacle":                              # 50 exp(-|r|^2 / 2)
+    val = 50.0 * torch.exp(-0.5 * s2)
+    rbar = r * (val * -float(coef))[:, None]
+  elif subtype == "double_well":                           # (|r - a| |r + a| / 2)^2 = sm sp / 4
+    sm, sp = ((r - a) ** 2).sum(1), ((r + a) ** 2).sum(1)
+    val = 0.25 * sm * sp
+    rbar = (0.5 * float(coef)) * ((r - a) * sp[:, None] + (r + a) * sm[:, None])
+  else:
+    raise ValueError(f"unknown potential {subtype!r}")
+  be.pass_vjp(zr, c, rbar.contiguous(), None, False, grad=ctx.grad, want_xbar=False)
+  return val.double().view(S, -1).sum(1)
+
+
 def _kl_sum(ctx, T, cond, batch_size, source, coef):
   z, start, count = ctx.noise(batch_size)
   key = ("source", batch_size, source)       # the same key draws the same source samples for every condition
@@ -141,6 +210,8 @@ def _kl_sum(ctx, T, cond, batch_size, source, coef):
     samples = z
   else:
     samples = s1 * ((T - cond) / T) + z * (cond / T)      # target N(0,I) drawn from the same key
+  if _use_table_backward(ctx, z.shape[1], count, 1):
+    return _neg_logprob_tables(ctx, samples.contiguous(), cond, coef)
   return ctx.terms(_spec(_capi.TERM_NEG_LOGPROB), samples.contiguous(), [cond], count, coef)
 
 
@@ -155,11 +226,15 @@ def _potential_sum(ctx, a, subtype, conds, batch_size, coef):
   if subtype not in _capi.POTENTIALS:
     raise ValueError(f"unknown potential {subtype!r}")
   z, _, count = ctx.noise(batch_size)
+  if _use_table_backward(ctx, z.shape[1], count, len(conds)):
+    return _potential_tables(ctx, z, conds, count, subtype, a, coef)
   return ctx.terms(_spec(_capi.TERM_POTENTIAL, subtype=_capi.POTENTIALS[subtype], a=a), z, conds, count, coef)
 
 
 def _kinetic_sum(ctx, dt, conds, batch_size, coef):
   z, _, count = ctx.noise(batch_size)
+  if _use_table_backward(ctx, z.shape[1], count, len(np.atleast_1d(conds)), passes=2):
+    return _kinetic_tables(ctx, z, np.atleast_1d(conds), count, dt, coef)
   return ctx.terms(_spec(_capi.TERM_KINETIC, dt=dt), z, conds, count, coef)
 
 

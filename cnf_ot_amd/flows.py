@@ -83,7 +83,8 @@ class FlowEngine:
     self._flat_key = None
     self._reserved = {}               # stream -> table sets reserved (cnf_model_reserve)
     self._pwl_mode = 1
-    self._tables_ok = (cfg.dim == 2 and cfg.hidden_size == 16 and cfg.num_bins == 5 and cfg.mlp_num_layers == 2)
+    self._tables_ok = (cfg.dim == 2 and cfg.hidden_size == 16 and cfg.num_bins == 5 and cfg.mlp_num_layers == 2
+                       and not cfg.periodized)
 
   def __del__(self):
     h = getattr(self, "_h", None)

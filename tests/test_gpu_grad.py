@@ -355,3 +355,33 @@ def test_pass_vjp_table_form_matches_mlp_backward(dev, to_base):
   for lo, hi in ((0, 16), (16, 48), (48, 64), (64, 320), (320, 336), (336, 592), (592, 608), (608, 1200)):
     ref = g0[lo:hi].abs().max().item()
     assert (g2[lo:hi] - g0[lo:hi]).abs().max().item() <= 1e-4 * max(ref, 1e-3 * g0.abs().max().item()), (lo, hi)
+
+
+@pytest.mark.parametrize("subtype", ["free", "obstacle"])
+def test_value_and_grad_through_the_table_backward(dev, subtype, monkeypatch):
+  """ot_loss_fn at dim 2 with its terms composed from table-path launches + cnf_pass_vjp on the tables
+  (applications._neg_logprob_tables / _kinetic_tables / _potential_tables; chosen for large batches, forced here):
+  same loss and the same gradient as the fused gradient kernel."""
+  from cnf_ot_amd import RQSFlow, Params, applications as app
+  model = RQSFlow(event_shape=(2,), num_layers=2, hidden_sizes=[16, 16], num_bins=5)
+  params = Params.random(model.cfg, 0.15, seed=9, device=dev)
+  B, tbs = 65536, 3
+  f = lambda p, rng, lam, bs, **kw: app.ot_loss_fn(model, 2, 1.0, 0.01, tbs, subtype, p, rng, lam, bs, source="gaussian", **kw)
+  vg = app.value_and_grad(f)
+  be = model.terms_backend(params)
+  be.set_pwl(0)
+  loss0, g0 = vg(params, 11, 50.0, B)
+  used = []
+  monkeypatch.setattr(app, "TABLE_BACKWARD_MIN_SLICE", 256)
+  monkeypatch.setattr(app, "TABLE_BACKWARD_MIN_POINTS", 256)
+  orig = be.pass_vjp
+  monkeypatch.setattr(be, "pass_vjp", lambda *a, **k: (used.append(1), orig(*a, **k))[1])
+  be.set_pwl(2)
+  loss2, g2 = vg(params, 11, 50.0, B)
+  torch.cuda.synchronize()
+  be.set_pwl(1)
+  assert len(used) >= 3 and be.last_path() == "tables"      # two density-fit terms + kinetic (+ obstacle)
+  el = abs(float(loss2) - float(loss0)) / abs(float(loss0))
+  eg = (g2.flat - g0.flat).abs().max().item() / g0.flat.abs().max().item()
+  print(f"\n[ot {subtype}: table backward vs fused kernel] loss rel {el:.2e} grad rel {eg:.2e}")
+  assert el <= 2e-5 and eg <= 2e-4
