@@ -217,7 +217,7 @@ def _kl_sum(ctx, T, cond, batch_size, source, coef):
 
 def _reverse_kl_sum(ctx, T, beta, cond, batch_size, coef):
   z, _, count = ctx.noise(batch_size)
-  if _use_unfused(ctx, z.shape[1]) and count <= UNFUSED_RKL_MAX_BATCH:
+  if (_use_unfused(ctx, z.shape[1]) and count <= UNFUSED_RKL_MAX_BATCH) or _use_table_backward(ctx, z.shape[1], count, 1):
     return _reverse_kl_unfused(ctx, T, beta, cond, batch_size, coef)
   return ctx.terms(_spec(_capi.TERM_REVERSE_KL, T=T, beta=beta), z, [cond], count, coef)
 

@@ -319,19 +319,19 @@ def test_logprob_fd_score_and_its_backward(dev, D, B):
     assert rel_p <= 1e-4 and rel_x <= 1e-4
 
 
+@pytest.mark.parametrize("L,S,Bs", [(2, 5, 6002), (3, 70, 1500)])
 @pytest.mark.parametrize("to_base", [False, True])
-def test_pass_vjp_table_form_matches_mlp_backward(dev, to_base):
+def test_pass_vjp_table_form_matches_mlp_backward(dev, to_base, L, S, Bs):
   """cnf_pass_vjp at dim 2 on the conditioner tables: per-piece sufficient statistics (A = sum theta_bar,
   B = sum (u - u_ref) theta_bar) instead of per-sample weight gradients (algebra restated and checked
   on the CPU in oracle/pwl_grad.py).  Same input adjoints and the same parameter gradient as the MLP backward, on
   slices of ragged length with a partial last slice."""
   from cnf_ot_amd import FlowConfig, FlowEngine, Params
-  cfg = FlowConfig(dim=2)
+  cfg = FlowConfig(dim=2, num_layers=L)      # (L = 3, 70 slices: two chunks of the 64-slice statistics buffer)
   params = Params.random(cfg, 0.2, seed=5, device=dev)
   eng = FlowEngine(cfg, dev).load(params)
   gen = torch.Generator(device="cpu").manual_seed(3)
-  S, Bs = 5, 6002                          # slices of 5 full tiles of 1 024 + a partial one
-  B = S * Bs
+  B = S * Bs                                 # slices of full tiles of 1 024 + a partial one
   pts = torch.randn(B, 2, generator=gen).to(dev) * (1.0 if not to_base else 1.5)
   ts = torch.linspace(0.1, 0.9, S).to(dev)
   ybar = torch.randn(B, 2, generator=gen).to(dev)
@@ -352,12 +352,16 @@ def test_pass_vjp_table_form_matches_mlp_backward(dev, to_base):
   print(f"\n[pass_vjp tables vs mlp, to_base={to_base}] xbar rel {ex:.2e}  grad rel {eg:.2e}  |g|inf {g0.abs().max().item():.3g}")
   assert ex <= 2e-5 and eg <= 5e-5
   # the `first` block and every tensor of a conditioner individually (a wrong row would hide in the maximum)
-  for lo, hi in ((0, 16), (16, 48), (48, 64), (64, 320), (320, 336), (336, 592), (592, 608), (608, 1200)):
+  blocks = [(0, 16)]
+  for l in range(L):
+    o = 16 + 592 * l
+    blocks += [(o, o + 32), (o + 32, o + 48), (o + 48, o + 304), (o + 304, o + 320), (o + 320, o + 576), (o + 576, o + 592)]
+  for lo, hi in blocks:
     ref = g0[lo:hi].abs().max().item()
     assert (g2[lo:hi] - g0[lo:hi]).abs().max().item() <= 1e-4 * max(ref, 1e-3 * g0.abs().max().item()), (lo, hi)
 
 
-@pytest.mark.parametrize("subtype", ["free", "obstacle"])
+@pytest.mark.parametrize("subtype", ["free", "obstacle", "rwpo"])
 def test_value_and_grad_through_the_table_backward(dev, subtype, monkeypatch):
   """ot_loss_fn at dim 2 with its terms composed from table-path launches + cnf_pass_vjp on the tables
   (applications._neg_logprob_tables / _kinetic_tables / _potential_tables; chosen for large batches, forced here):
@@ -366,7 +370,10 @@ def test_value_and_grad_through_the_table_backward(dev, subtype, monkeypatch):
   model = RQSFlow(event_shape=(2,), num_layers=2, hidden_sizes=[16, 16], num_bins=5)
   params = Params.random(model.cfg, 0.15, seed=9, device=dev)
   B, tbs = 65536, 3
-  f = lambda p, rng, lam, bs, **kw: app.ot_loss_fn(model, 2, 1.0, 0.01, tbs, subtype, p, rng, lam, bs, source="gaussian", **kw)
+  if subtype == "rwpo":      # reverse KL + potential through the tables (the finite-difference score term stays fused)
+    f = lambda p, rng, lam, bs, **kw: app.rwpo_loss_fn(model, 2, 1.0, 1.0, 0.01, 0.01, tbs, "quadratic", 1.0, p, rng, lam, bs, **kw)
+  else:
+    f = lambda p, rng, lam, bs, **kw: app.ot_loss_fn(model, 2, 1.0, 0.01, tbs, subtype, p, rng, lam, bs, source="gaussian", **kw)
   vg = app.value_and_grad(f)
   be = model.terms_backend(params)
   be.set_pwl(0)
@@ -380,7 +387,7 @@ def test_value_and_grad_through_the_table_backward(dev, subtype, monkeypatch):
   loss2, g2 = vg(params, 11, 50.0, B)
   torch.cuda.synchronize()
   be.set_pwl(1)
-  assert len(used) >= 3 and be.last_path() == "tables"      # two density-fit terms + kinetic (+ obstacle)
+  assert len(used) >= (2 if subtype == "rwpo" else 3)      # two density-fit terms + kinetic (+ obstacle); rkl + potential
   el = abs(float(loss2) - float(loss0)) / abs(float(loss0))
   eg = (g2.flat - g0.flat).abs().max().item() / g0.flat.abs().max().item()
   print(f"\n[ot {subtype}: table backward vs fused kernel] loss rel {el:.2e} grad rel {eg:.2e}")
