@@ -636,6 +636,7 @@ struct VjpPwlArgs {
   float* xbar;           // [B, 2] or null
   const float* tables;   // [n_slices][L][PWL_TBL]
   stat_t* stats;         // [n_slices][L][PWL_NPIECE][PWL_STAT] fixed point, zero on entry
+  stat_t* coarse;        // the same shape at 2^-32 of the scale: terms too large for `stats` (ill-conditioned flows)
   const uint32_t* amax;  // bits of the largest |adjoint| of the call (adjoint_max_kernel)
   float* first_acc;      // [GP] per-bin adjoint sums of the `first` spline (a slab's first entries), zero on entry
   int64_t B, slice_len;
@@ -659,9 +660,27 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
   const SplineConsts sc = sc_scalars(a.m.sc);
   // fixed-point scale 2^(28 - e), e = the exponent of the largest adjoint; x -> round(x scale) by the 1.5 2^52 trick
   const double fx_scale = stat_scale(*a.amax);
-  auto to_fixed = [&](float x) -> stat_t {
-    const double d = fma((double)x, fx_scale, 6755399441055744.0);
+  auto to_fixed = [&](double xs) -> stat_t {              // xs = x scale, |xs| < 2^50
+    const double d = xs + 6755399441055744.0;
     return (stat_t)(__double_as_longlong(d) - __double_as_longlong(6755399441055744.0));
+  };
+  // one term into accumulator `e` of (slice, layer l, piece p): LDS for the first PWL_ACC_W pieces; a term beyond the
+  // fine scale's reach (|x| >= 2^22 x the largest adjoint: only ill-conditioned flows produce them) goes, 2^32
+  // coarser, to the second statistics array in global memory
+  auto accumulate = [&](int slice, int l, int p, int e, float x) {
+    const double xs = (double)x * fx_scale;
+    if (fabs(xs) < 1125899906842624.0) {                     // 2^50
+      const stat_t q = to_fixed(xs);
+      if (p < PWL_ACC_W) {
+        typedef stat_t __attribute__((address_space(3))) * lds_q_ptr;
+        lds_q_ptr d3 = (lds_q_ptr)(uintptr_t)(uint32_t)(uintptr_t)(acc + (l * PWL_ACC_W + p) * PWL_STAT_LDS + e);
+        __hip_atomic_fetch_add(d3, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        atomicAdd(a.stats + (((int64_t)slice * L + l) * PWL_NPIECE + p) * PWL_STAT + e, q);
+      }
+    } else if (fabs(xs) < 4835703278458516698824704.0) {     // 2^82
+      atomicAdd(a.coarse + (((int64_t)slice * L + l) * PWL_NPIECE + p) * PWL_STAT + e, to_fixed(xs * 2.3283064365386963e-10));
+    }                                                         // (beyond: not representable in float32 sums either)
   };
   FirstAcc fa;
 #pragma unroll
@@ -762,21 +781,9 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
         for (int m2 = 0; m2 < PWL_P; ++m2) ucond_bar = fmaf(S[m2], tb[m2], ucond_bar);
 #ifndef CNF_VJP_PWL_NO_ATOMICS     /* experiment switch: what the accumulation costs */
         if (valid) {
-          stat_t* dst = p < PWL_ACC_W ? acc + (l * PWL_ACC_W + p) * PWL_STAT_LDS
-                                      : a.stats + (((int64_t)slice * L + l) * PWL_NPIECE + p) * PWL_STAT;
 #pragma unroll
           for (int m2 = 0; m2 < PWL_P; ++m2) {
-            if (tb[m2] != 0.0f) {
-              const stat_t qa = to_fixed(tb[m2]), qb = to_fixed(du * tb[m2]);
-              if (p < PWL_ACC_W) {          // LDS: ds_add_u64
-                typedef stat_t __attribute__((address_space(3))) * lds_q_ptr;
-                lds_q_ptr d3 = (lds_q_ptr)(uintptr_t)(uint32_t)(uintptr_t)dst;
-                __hip_atomic_fetch_add(d3 + m2, qa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(d3 + PWL_P + m2, qb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              } else {                      // a piece without LDS accumulators: straight to the slice's statistics
-                atomicAdd(dst + m2, qa); atomicAdd(dst + PWL_P + m2, qb);
-              }
-            }
+            if (tb[m2] != 0.0f) { accumulate(slice, l, p, m2, tb[m2]); accumulate(slice, l, p, PWL_P + m2, du * tb[m2]); }
           }
         }
 #endif
@@ -822,6 +829,7 @@ struct StatsFinishArgs {
   const float* cvals;    // [n_slices]
   const float* tables;
   stat_t* stats;
+  stat_t* coarse;
   const uint32_t* amax;
   float* slabs;          // [1 + n_slices * L][n_params]
   int64_t n_params;
@@ -850,10 +858,12 @@ __global__ __launch_bounds__(256) void pwl_stats_finish_kernel(const StatsFinish
   stat_t* st = a.stats + (int64_t)blockIdx.x * PWL_NPIECE * PWL_STAT;
   const int n = __float_as_int(T[PWL_N_SLOT]);
   const double inv_scale = 1.0 / stat_scale(*a.amax);
+  stat_t* sc2 = a.coarse + (int64_t)blockIdx.x * PWL_NPIECE * PWL_STAT;
   for (int i = tid; i < (n + 1) * PWL_STAT; i += blockDim.x) {
-    const stat_t q = st[i];
-    stat[i] = (float)((double)(long long)q * inv_scale);
+    const stat_t q = st[i], qc = sc2[i];
+    stat[i] = (float)(((double)(long long)q + (double)(long long)qc * 4294967296.0) * inv_scale);
     if (q != 0) st[i] = 0;                                 // cleared for the next call
+    if (qc != 0) sc2[i] = 0;
   }
   __syncthreads();
   float out[PER_LANE];
@@ -1192,8 +1202,8 @@ extern "C" int cnf_grad_enable(CnfModel* m, int64_t max_blocks) {
   // the table backward of dim-2 passes (vjp_pwl_kernel): per-piece statistics of PWL_STAT_SLICES slices, kept zero
   // between calls (pwl_stats_finish_kernel clears what it reads)
   if (!m->pwl_stats && m->cfg.dim == 2 && m->cfg.num_layers <= 4 && m->cfg.mlp_num_layers == 2) {
-    // [64 bytes: the call's largest adjoint][statistics]
-    const size_t bytes = 64 + sizeof(stat_t) * (size_t)PWL_STAT_SLICES * m->cfg.num_layers * PWL_NPIECE * PWL_STAT;
+    // [64 bytes: the call's largest adjoint][statistics][coarse statistics]
+    const size_t bytes = 64 + 2 * sizeof(stat_t) * (size_t)PWL_STAT_SLICES * m->cfg.num_layers * PWL_NPIECE * PWL_STAT;
     if (hipMalloc((void**)&m->pwl_stats, bytes) == hipSuccess) {
       if (hipMemset(m->pwl_stats, 0, bytes) != hipSuccess) { (void)hipFree(m->pwl_stats); m->pwl_stats = nullptr; }
     } else {
@@ -1254,7 +1264,8 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     a.xbar = xbar ? xbar + 2 * first : nullptr;
     uint32_t* amax = reinterpret_cast<uint32_t*>(m->pwl_stats);
     stat_t* stats = reinterpret_cast<stat_t*>(reinterpret_cast<char*>(m->pwl_stats) + 64);
-    a.tables = tables; a.stats = stats; a.amax = amax; a.first_acc = m->grad_slabs;
+    stat_t* coarse = stats + (size_t)PWL_STAT_SLICES * L * PWL_NPIECE * PWL_STAT;
+    a.tables = tables; a.stats = stats; a.coarse = coarse; a.amax = amax; a.first_acc = m->grad_slabs;
     a.B = (B - first) < ns * slice_len ? (B - first) : ns * slice_len;
     a.slice_len = slice_len; a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps;
     if (hipMemsetAsync(amax, 0, 4, stream) != hipSuccess) return CNF_ERR_HIP;
@@ -1266,7 +1277,7 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     else hipLaunchKernelGGL(vjp_pwl_kernel<false>, dim3((unsigned)grid), dim3(threads), lds, stream, a);
     StatsFinishArgs f;
     f.weights = m->prep + hdr_floats(GK); f.per_layer = m->per_layer; f.cvals = c + s0; f.tables = tables;
-    f.stats = stats; f.amax = amax; f.slabs = m->grad_slabs; f.n_params = m->n_params; f.L = L;
+    f.stats = stats; f.coarse = coarse; f.amax = amax; f.slabs = m->grad_slabs; f.n_params = m->n_params; f.L = L;
     hipLaunchKernelGGL(pwl_stats_finish_kernel, dim3((unsigned)(ns * L)), dim3(256), 0, stream, f);
     const int fb = (int)((m->n_params + 31) / 32);
     hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, 1 + ns * L, m->n_params,
