@@ -638,7 +638,8 @@ struct VjpPwlArgs {
   stat_t* stats;         // [n_slices][L][PWL_NPIECE][PWL_STAT] fixed point, zero on entry
   stat_t* coarse;        // the same shape at 2^-32 of the scale: terms too large for `stats` (ill-conditioned flows)
   const uint32_t* amax;  // bits of the largest |adjoint| of the call (adjoint_max_kernel)
-  float* first_acc;      // [GP] per-bin adjoint sums of the `first` spline (a slab's first entries), zero on entry
+  float* slabs;          // slab b (this workgroup's): zeroed here, its first GP entries receive the `first` spline's
+  int64_t n_params;      // per-bin adjoint sums (one owner per slab: a fixed summation order)
   int64_t B, slice_len;
   int32_t n_slices, tiles_per_slice;
 };
@@ -813,16 +814,18 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
       for (int j = 0; j < GP; ++j) red[(tid >> 6) * GP + j] = r[j];
     }
     __syncthreads();
+    float* slab = a.slabs + (int64_t)blockIdx.x * a.n_params;
+    for (int64_t i = GP + tid; i < a.n_params; i += NT) slab[i] = 0.0f;
     if (tid < GP) {
       float s = 0.0f;
       for (int w2 = 0; w2 < (NT >> 6); ++w2) s += red[w2 * GP + tid];
-      unsafeAtomicAdd(a.first_acc + tid, s);
+      slab[tid] = s;
     }
   }
 }
 
 // One block per (slice, layer): the slice's per-piece statistics -> that layer's 592 conditioner gradients, written
-// (with zeros elsewhere) into slab 1 + block; the statistics are cleared for the next call.
+// (with zeros elsewhere) into slab first_slab + block; the statistics are cleared for the next call.
 struct StatsFinishArgs {
   const float* weights;  // prep + hdr: the conditioner weights snapshot
   int64_t per_layer;
@@ -831,9 +834,9 @@ struct StatsFinishArgs {
   stat_t* stats;
   stat_t* coarse;
   const uint32_t* amax;
-  float* slabs;          // [1 + n_slices * L][n_params]
+  float* slabs;          // [first_slab + n_slices * L][n_params]
   int64_t n_params;
-  int32_t L;
+  int32_t L, first_slab;
 };
 
 __global__ __launch_bounds__(256) void pwl_stats_finish_kernel(const StatsFinishArgs a) {
@@ -922,7 +925,7 @@ __global__ __launch_bounds__(256) void pwl_stats_finish_kernel(const StatsFinish
   for (int q = 0; q < PER_LANE; ++q) { const int o = lane + q * 64; if (o < NW) part[wv][o] = out[q]; }
   __syncthreads();
   // slab 1 + block: zeros except this layer's conditioner
-  float* slab = a.slabs + (int64_t)(1 + blockIdx.x) * a.n_params;
+  float* slab = a.slabs + (int64_t)(a.first_slab + blockIdx.x) * a.n_params;
   const int64_t base = GP + (int64_t)l * a.per_layer;
   for (int64_t i = tid; i < a.n_params; i += blockDim.x) {
     const int64_t o = i - base;
@@ -1256,7 +1259,6 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     const int r = cnf_internal_build_tables(m, stream, c + s0, ns, &tables);
     if (r != CNF_OK) return s0 == 0 ? r : CNF_ERR_HIP;          // (a later chunk cannot fail on its own)
     m->last_path = CNF_PATH_TABLES;
-    if (hipMemsetAsync(m->grad_slabs, 0, sizeof(float) * (size_t)m->n_params, stream) != hipSuccess) return CNF_ERR_HIP;
     const int64_t first = s0 * slice_len;
     VjpPwlArgs a;
     a.m = model_args(m);
@@ -1265,7 +1267,7 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     uint32_t* amax = reinterpret_cast<uint32_t*>(m->pwl_stats);
     stat_t* stats = reinterpret_cast<stat_t*>(reinterpret_cast<char*>(m->pwl_stats) + 64);
     stat_t* coarse = stats + (size_t)PWL_STAT_SLICES * L * PWL_NPIECE * PWL_STAT;
-    a.tables = tables; a.stats = stats; a.coarse = coarse; a.amax = amax; a.first_acc = m->grad_slabs;
+    a.tables = tables; a.stats = stats; a.coarse = coarse; a.amax = amax; a.slabs = m->grad_slabs; a.n_params = m->n_params;
     a.B = (B - first) < ns * slice_len ? (B - first) : ns * slice_len;
     a.slice_len = slice_len; a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps;
     if (hipMemsetAsync(amax, 0, 4, stream) != hipSuccess) return CNF_ERR_HIP;
@@ -1273,14 +1275,16 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
                        a.ldbar ? a.B : 0, amax);
     const int64_t tiles = ns * tps;
     const int64_t grid = tiles < m->num_cus ? tiles : m->num_cus;
+    if (grid + ns * L > m->grad_max_blocks * 4) return s0 == 0 ? CNF_ERR_UNSUPPORTED : CNF_ERR_HIP;      // (slabs: cnf_grad_enable)
     if (to_base) hipLaunchKernelGGL(vjp_pwl_kernel<true>, dim3((unsigned)grid), dim3(threads), lds, stream, a);
     else hipLaunchKernelGGL(vjp_pwl_kernel<false>, dim3((unsigned)grid), dim3(threads), lds, stream, a);
     StatsFinishArgs f;
     f.weights = m->prep + hdr_floats(GK); f.per_layer = m->per_layer; f.cvals = c + s0; f.tables = tables;
     f.stats = stats; f.coarse = coarse; f.amax = amax; f.slabs = m->grad_slabs; f.n_params = m->n_params; f.L = L;
+    f.first_slab = (int32_t)grid;
     hipLaunchKernelGGL(pwl_stats_finish_kernel, dim3((unsigned)(ns * L)), dim3(256), 0, stream, f);
     const int fb = (int)((m->n_params + 31) / 32);
-    hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, 1 + ns * L, m->n_params,
+    hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, grid + ns * L, m->n_params,
                        params, grad, (double)m->sc.span_eff, (double)m->sc.sp_offset);
     if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
   }

@@ -346,6 +346,11 @@ def test_pass_vjp_table_form_matches_mlp_backward(dev, to_base, L, S, Bs):
     torch.cuda.synchronize()
     res[mode] = (xbar, g, eng.last_path())
   assert res[2][2] == "tables" and res[0][2] != "tables"
+  # fixed-point statistics and one owner per slab: the same bits every time
+  eng.set_pwl(2)
+  g_again = torch.zeros(cfg.param_count(), device=dev)
+  eng.pass_vjp(pts, ts, ybar, ldbar, to_base, grad=g_again, want_xbar=False)
+  assert torch.equal(g_again, res[2][1])
   xb0, g0, _ = res[0]; xb2, g2, _ = res[2]
   ex = (xb2 - xb0).abs().max().item() / xb0.abs().max().item()
   eg = (g2 - g0).abs().max().item() / g0.abs().max().item()
