@@ -151,10 +151,10 @@ def _neg_logprob_tables(ctx, samples, cond, coef):
   be = ctx.be
   c = be.slice_conds([cond])
   x, ildj = be.inverse_logdet(samples, c)
-  lp = ildj.double() - 0.5 * (x.double() ** 2).sum(1) - np.log(2.0 * np.pi)
+  lp = ildj - 0.5 * (x * x).sum(1) - float(np.log(2.0 * np.pi))      # per sample in float32 (as the fused term), summed in float64
   # d(-sum lp) scaled by coef: lp_bar = -coef; x_bar = lp_bar * d base/dx = coef * x; ld_bar = -coef
   be.pass_vjp(samples, c, x * float(coef), torch.full_like(ildj, -float(coef)), True, grad=ctx.grad, want_xbar=False)
-  return -lp.sum().reshape(1)
+  return -lp.sum(dtype=torch.float64).reshape(1)
 
 
 def _kinetic_tables(ctx, z, conds, count, dt, coef):
@@ -168,7 +168,7 @@ def _kinetic_tables(ctx, z, conds, count, dt, coef):
   r, _ = be.forward_logdet(z2, c2, want_logdet=False)
   n = S * count
   v = (r[n:] - r[:n]) * (1.0 / dt)
-  sums = (v.double() ** 2).view(S, -1).sum(1)
+  sums = (v * v).view(S, -1).sum(1, dtype=torch.float64)
   g = v * (2.0 * float(coef) / dt)                         # d(coef * sum v^2) / d r2 = -d / d r1
   be.pass_vjp(z2, c2, torch.cat([-g, g]), None, False, grad=ctx.grad, want_xbar=False)
   return sums
@@ -195,7 +195,7 @@ def _potential_tables(ctx, z, conds, count, subtype, a, coef):
   else:
     raise ValueError(f"unknown potential {subtype!r}")
   be.pass_vjp(zr, c, rbar.contiguous(), None, False, grad=ctx.grad, want_xbar=False)
-  return val.double().view(S, -1).sum(1)
+  return val.view(S, -1).sum(1, dtype=torch.float64)
 
 
 def _kl_sum(ctx, T, cond, batch_size, source, coef):

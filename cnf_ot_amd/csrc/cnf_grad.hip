@@ -612,17 +612,23 @@ __device__ __forceinline__ double stat_scale(uint32_t amax_bits) {
 }
 
 // the largest |ybar|, |ldbar| of a call (bit pattern of a non-negative float: ordered like the integers)
-__global__ void adjoint_max_kernel(const float* __restrict__ ybar, int64_t n_y, const float* __restrict__ ldbar,
-                                   int64_t n_l, uint32_t* out) {
+__global__ __launch_bounds__(256) void adjoint_max_kernel(const float* __restrict__ ybar, int64_t n_y,
+                                                         const float* __restrict__ ldbar, int64_t n_l, uint32_t* out) {
   uint32_t m = 0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_y; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t b = __float_as_uint(ybar[i]) & 0x7fffffffu;
-    m = b > m && b < 0x7f800000u ? b : m;
-  }
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_l; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t b = __float_as_uint(ldbar[i]) & 0x7fffffffu;
-    m = b > m && b < 0x7f800000u ? b : m;
-  }
+  auto take = [&](float v) { const uint32_t b = __float_as_uint(v) & 0x7fffffffu; m = (b > m && b < 0x7f800000u) ? b : m; };
+  auto scan = [&](const float* __restrict__ p, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {            // 16-byte loads, four in flight per thread
+      const f4* q = reinterpret_cast<const f4*>(p);
+      const int64_t n4 = n >> 2;
+      for (int64_t i = t; i < n4; i += stride) { const f4 v = q[i]; take(v[0]); take(v[1]); take(v[2]); take(v[3]); }
+      for (int64_t i = (n4 << 2) + t; i < n; i += stride) take(p[i]);
+    } else {
+      for (int64_t i = t; i < n; i += stride) take(p[i]);
+    }
+  };
+  if (ybar) scan(ybar, n_y);
+  if (ldbar) scan(ldbar, n_l);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
   if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
@@ -1271,7 +1277,7 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     a.B = (B - first) < ns * slice_len ? (B - first) : ns * slice_len;
     a.slice_len = slice_len; a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps;
     if (hipMemsetAsync(amax, 0, 4, stream) != hipSuccess) return CNF_ERR_HIP;
-    hipLaunchKernelGGL(adjoint_max_kernel, dim3(256), dim3(256), 0, stream, a.ybar, a.ybar ? 2 * a.B : 0, a.ldbar,
+    hipLaunchKernelGGL(adjoint_max_kernel, dim3((unsigned)(m->num_cus * 4)), dim3(256), 0, stream, a.ybar, a.ybar ? 2 * a.B : 0, a.ldbar,
                        a.ldbar ? a.B : 0, amax);
     const int64_t tiles = ns * tps;
     const int64_t grid = tiles < m->num_cus ? tiles : m->num_cus;
