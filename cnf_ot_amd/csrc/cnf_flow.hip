@@ -275,7 +275,9 @@ __device__ __forceinline__ v2f hsum(v2f v) { return v; }
 // Returns the accumulated log|det J|; the result is left in `U` (swapped).
 // PRECISE (TO_BASE only): the precise position path of cnf_device.h; `e2tab` is its 2^(-i/32) table in LDS and
 // `bacc` receives sum_d x_d^2 of the recovered base point in float64.
-template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false, bool PRECISE = false, bool PERIODIC = false>
+// DFIX > 0: the event dimension is this compile-time constant (the single-batch kernel at dim 2: the dimension
+// loop, the conditioner offsets and the tile transposes lose their runtime arithmetic)
+template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false, bool PRECISE = false, bool PERIODIC = false, int DFIX = 0>
 __device__ __forceinline__ T flow_pass(const ModelArgs& a, const typename Lanes<T>::real* tab,
                                        typename Lanes<T>::real*& U, typename Lanes<T>::real*& O, T c,
                                        const double* e2tab = nullptr, const double* tabd = nullptr,
@@ -290,7 +292,7 @@ __device__ __forceinline__ T flow_pass(const ModelArgs& a, const typename Lanes<
   constexpr int SPL = Lanes<T>::N;
   constexpr int TS = TILE * SPL;
   uniform_ptr weights = as_uniform(a.prep + hdr_floats(K));
-  const int D = a.D;
+  const int D = DFIX ? DFIX : a.D;
   T acc = splat<T>(0.0f);
   for (int step = 0; step < a.L; ++step) {
     const int l = TO_BASE ? a.L - 1 - step : step;
@@ -365,7 +367,7 @@ __device__ __forceinline__ void store_aux(float* aux, int64_t i, int64_t B, v2f 
   else { if (i < B) aux[i] = r.x; if (i + 1 < B) aux[i + 1] = r.y; }
 }
 
-template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false, bool PRECISE = false, bool PERIODIC = false>
+template <int H, int K, bool TO_BASE, bool FAST, class T, bool MFMA = false, bool PRECISE = false, bool PERIODIC = false, int DFIX = 0>
 __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename Lanes<T>::real> a) {
   typedef typename Lanes<T>::real R;
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
@@ -373,17 +375,19 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
   constexpr int HDR = hdr_floats(K);
   constexpr int SPL = Lanes<T>::N;
   constexpr int TS = TILE * SPL;
+  const int DD = DFIX ? DFIX : a.m.D;
+  const uint32_t dmagic = DFIX == 2 ? 0x80000000u : (uint32_t)a.div_magic;
   R* tab = lds;
   R* U = lds + HDR;
-  R* O = U + a.m.D * TS;
+  R* O = U + DD * TS;
   if (gate_closed(a)) return;
   for (int i = threadIdx.x; i < HDR; i += TILE) tab[i] = table_of<R>(a.m)[i];
   [[maybe_unused]] double* e2tab = nullptr;
   [[maybe_unused]] double* tabd = nullptr;
   [[maybe_unused]] R* LO = nullptr;
   if constexpr (PRECISE) {      // [.. U O][LO][2^(-i/32) table][float64 `first` table]; HDR, D * TS even: 8-byte aligned
-    LO = O + a.m.D * TS;
-    e2tab = reinterpret_cast<double*>(LO + a.m.D * TS);
+    LO = O + DD * TS;
+    e2tab = reinterpret_cast<double*>(LO + DD * TS);
     tabd = e2tab + EXP2_N;
     for (int i = threadIdx.x; i < EXP2_N; i += TILE) e2tab[i] = a.m.e2tab[i];
     for (int i = threadIdx.x; i < HDR; i += TILE) tabd[i] = a.m.tabd[i];
@@ -394,28 +398,28 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
     const int64_t tile_start = tile * TS;
     const int64_t i = tile_start + SPL * threadIdx.x;
     __syncthreads();                       // previous tile's stores are done with U/O
-    if (TO_BASE && !PRECISE && a.fd2) tile_load_fd<R>(a, U, a.m.D, a.div_magic, TS, tile_start);
-    else tile_load<R>(a.in, U, a.m.D, a.div_magic, TS, tile_start, a.B);
+    if (TO_BASE && !PRECISE && a.fd2) tile_load_fd<R>(a, U, DD, dmagic, TS, tile_start);
+    else tile_load<R>(a.in, U, DD, dmagic, TS, tile_start, a.B);
     const T c = load_cond<T>(a, tile_start, i);
     __syncthreads();
 
     T base = splat<T>(0.0f);
-    if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = base_logprob<T>(U + SPL * threadIdx.x, a.m.D, TS);
+    if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = base_logprob<T>(U + SPL * threadIdx.x, DD, TS);
     BaseAcc<T> bacc;
-    const T acc = flow_pass<H, K, TO_BASE, FAST, T, MFMA, PRECISE, PERIODIC>(a.m, tab, U, O, c, e2tab, tabd, LO, &bacc);
+    const T acc = flow_pass<H, K, TO_BASE, FAST, T, MFMA, PRECISE, PERIODIC, DFIX>(a.m, tab, U, O, c, e2tab, tabd, LO, &bacc);
     if (a.aux) {
       T r = acc;
       if (a.aux_mode == AUX_LOGPROB) {
         // log_prob = base(x) + ildj (conditional.py:316-321); lp_y = lp_x - fldj (:399-401)
-        if constexpr (PRECISE) r = bacc.log_prob(acc, a.m.D);
-        else r = TO_BASE ? base_logprob<T>(U + SPL * threadIdx.x, a.m.D, TS) + acc : base - acc;
+        if constexpr (PRECISE) r = bacc.log_prob(acc, DD);
+        else r = TO_BASE ? base_logprob<T>(U + SPL * threadIdx.x, DD, TS) + acc : base - acc;
       }
       if (TO_BASE && !PRECISE && a.fd2) store_fd(a, i, r);
       else store_aux(a.aux, i, a.B, r);
     }
     if (a.out) {
       __syncthreads();
-      tile_store<R>(a.out, U, a.m.D, a.div_magic, TS, tile_start, a.B);
+      tile_store<R>(a.out, U, DD, dmagic, TS, tile_start, a.B);
     }
   }
 }
@@ -1495,11 +1499,14 @@ static int launch_flow(CnfModel* m, const FlowArgs& a, int spl, hipStream_t stre
       m->cfg.hidden_size == 16 && m->cfg.num_bins == 5) {
     if (!a.gate) m->last_path = CNF_PATH_MFMA;
     ProfScope ps(m, stream, false, a.B, CNF_PATH_MFMA);
+    const bool d2 = m->cfg.dim == 2 && spl == 1;        // the reference's per-batch call pattern: its own instantiation
     if (precise) {
       if (spl == 2) CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, v2f, true, PR>), grid, lds, stream, a);
+      else if (d2) CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, float, true, PR, false, 2>), grid, lds, stream, a);
       else CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, float, true, PR>), grid, lds, stream, a);
     } else {
       if (spl == 2) CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, v2f, true>), grid, lds, stream, a);
+      else if (d2) CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, float, true, false, false, 2>), grid, lds, stream, a);
       else CNF_LAUNCH((flow_kernel<16, 5, TO_BASE, true, float, true>), grid, lds, stream, a);
     }
     ps.done();
