@@ -93,10 +93,10 @@ __device__ __forceinline__ int64_t cond_prefix(int d) {      // floats of condit
 // conditioner code (the bulk) exists once, so the kernel fits the instruction
 // cache (the first version inlined 10 forward + 6 backward copies: 34 k
 // instructions, 4x the cache).
-template <bool FAST>
+template <bool FAST, int DFIX = 0>
 __device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, const float* tab, float* St, float c,
                                                 bool to_base) {
-  const int D = a.D;
+  const int D = DFIX ? DFIX : a.D;
   uniform_ptr weights = as_uniform(a.prep + hdr_floats(GK));
   float acc = 0.0f;
   for (int s = 0; s < a.L; ++s) {
@@ -134,11 +134,11 @@ __device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, const float*
 // backward of the pass whose stash is in St.  Aa holds the adjoint of the final
 // output on entry; the function ping-pongs between Aa and Ab and returns the
 // buffer that holds the adjoint of the pass input.
-template <bool FAST, bool WGRAD = true>
+template <bool FAST, bool WGRAD = true, int DFIX = 0>
 __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab, const float* St, float* Aa,
                                            float* Ab, float ld_bar, float c, bool to_base, float* gslab,
                                            float* stage, FirstAcc& fa) {
-  const int D = a.D;
+  const int D = DFIX ? DFIX : a.D;
   uniform_ptr weights = as_uniform(a.prep + hdr_floats(GK));
   float* Ao = Aa;
   float* Au = Ab;
@@ -245,11 +245,12 @@ enum Role {
   R_R3B, R_R2B, R_R1B   // backward of r3 / r2 / r1 (forward recomputed)
 };
 
-template <bool FAST>
+// DFIX > 0: the event dimension as a compile-time constant (dim 2: the reference's main configurations)
+template <bool FAST, int DFIX = 0>
 __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void grad_kernel(const GradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HDR = hdr_floats(GK);
-  const int D = a.m.D, L = a.m.L;
+  const int D = DFIX ? DFIX : a.m.D, L = a.m.L;
   const int DT = D * GTS;
   float* tab = lds;
   float* Nn = lds + HDR;
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void grad_kernel(const
       } else {
         for (int e = 0; e < D; ++e) s0[e * GTS] = n_[e * GTS];
       }
-      const float ldsum = pass_fwd_stash<FAST>(a.m, tab, St, c, to_base);
+      const float ldsum = pass_fwd_stash<FAST, DFIX>(a.m, tab, St, c, to_base);
       // ---- act on the result, prepare the seeds
       bool do_bwd = false;
       float ld_bar = 0.0f;
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void grad_kernel(const
           break;
       }
       if (do_bwd) {
-        const float* ain = pass_bwd<FAST>(a.m, tab, St, Aa, Ab, ld_bar, c, to_base, gslab, stage, fa) + tid;
+        const float* ain = pass_bwd<FAST, true, DFIX>(a.m, tab, St, Aa, Ab, ld_bar, c, to_base, gslab, stage, fa) + tid;
         if (role == R_LPM || role == R_LPPB)
           for (int e = 0; e < D; ++e) r3b[e * GTS] += ain[e * GTS];
       }
@@ -479,11 +480,11 @@ struct VjpArgs {
 
 // WGRAD=true additionally accumulates the parameter gradient of the pass (the
 // backward of a differentiable flow op: cnf_pass_vjp).
-template <bool FAST, bool WGRAD>
+template <bool FAST, bool WGRAD, int DFIX = 0>
 __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void vjp_kernel(const VjpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HDR = hdr_floats(GK);
-  const int D = a.m.D, L = a.m.L, DT = D * GTS;
+  const int D = DFIX ? DFIX : a.m.D, L = a.m.L, DT = D * GTS;
   float* tab = lds;
   float* St = lds + HDR;
   float* Aa = St + (L + 1) * DT;
@@ -527,12 +528,12 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void vjp_kernel(const 
       ld_bar = (a.ldbar && i < a.B) ? a.ldbar[i] : 0.0f;
     }
     __syncthreads();
-    pass_fwd_stash<FAST>(a.m, tab, St, c, a.to_base != 0);
+    pass_fwd_stash<FAST, DFIX>(a.m, tab, St, c, a.to_base != 0);
     if (a.fd2) {       // log_prob = sum -x^2/2 + ildj: the adjoint of the recovered base point is -ld_bar x
       const float* sL = St + L * DT + tid;
       for (int e = 0; e < D; ++e) Aa[e * GTS + tid] = -ld_bar * sL[e * GTS];
     }
-    float* ain = pass_bwd<FAST, WGRAD>(a.m, tab, St, Aa, Ab, ld_bar, c, a.to_base != 0, gslab, stage, fa);
+    float* ain = pass_bwd<FAST, WGRAD, DFIX>(a.m, tab, St, Aa, Ab, ld_bar, c, a.to_base != 0, gslab, stage, fa);
     __syncthreads();
     if (a.fd2) {       // xbar[i, e] = sum over the fd2 evaluation points of base point i (fixed order: deterministic)
       if (a.xbar) {
@@ -1187,8 +1188,13 @@ extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const f
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
   const int64_t n_slabs = grid * (ts / 64);
   if (m->fast_math) {
-    if (!ensure_lds(grad_kernel<true>, lds)) return CNF_ERR_HIP;
-    hipLaunchKernelGGL(grad_kernel<true>, dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    if (D == 2) {
+      if (!ensure_lds(grad_kernel<true, 2>, lds)) return CNF_ERR_HIP;
+      hipLaunchKernelGGL((grad_kernel<true, 2>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    } else {
+      if (!ensure_lds(grad_kernel<true>, lds)) return CNF_ERR_HIP;
+      hipLaunchKernelGGL(grad_kernel<true>, dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    }
   } else {
     if (!ensure_lds(grad_kernel<false>, lds)) return CNF_ERR_HIP;
     hipLaunchKernelGGL(grad_kernel<false>, dim3((unsigned)grid), dim3(ts), lds, stream, a);
@@ -1335,8 +1341,13 @@ static int pass_vjp_impl(CnfModel* m, int to_base, const float* pts, const float
   if (grid > m->grad_max_blocks * 4 / (ts / 64)) grid = m->grad_max_blocks * 4 / (ts / 64);
   const int64_t n_slabs = grid * (ts / 64);
   if (m->fast_math) {
-    if (!ensure_lds(vjp_kernel<true, true>, lds)) return CNF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((vjp_kernel<true, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    if (D == 2) {
+      if (!ensure_lds(vjp_kernel<true, true, 2>, lds)) return CNF_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL((vjp_kernel<true, true, 2>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    } else {
+      if (!ensure_lds(vjp_kernel<true, true>, lds)) return CNF_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL((vjp_kernel<true, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    }
   } else {
     if (!ensure_lds(vjp_kernel<false, true>, lds)) return CNF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((vjp_kernel<false, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
@@ -1387,8 +1398,13 @@ extern "C" int cnf_logprob_fd_vjp(CnfModel* m, const float* pts, const float* c,
   if (grid > m->grad_max_blocks * 4 / (ts / 64)) grid = m->grad_max_blocks * 4 / (ts / 64);
   const int64_t n_slabs = grid * (ts / 64);
   if (m->fast_math) {
-    if (!ensure_lds(vjp_kernel<true, true>, lds)) return CNF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((vjp_kernel<true, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    if (D == 2) {
+      if (!ensure_lds(vjp_kernel<true, true, 2>, lds)) return CNF_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL((vjp_kernel<true, true, 2>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    } else {
+      if (!ensure_lds(vjp_kernel<true, true>, lds)) return CNF_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL((vjp_kernel<true, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    }
   } else {
     if (!ensure_lds(vjp_kernel<false, true>, lds)) return CNF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((vjp_kernel<false, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
