@@ -79,6 +79,8 @@ SYMBOLS = {
   "cnf_logprob_fd_vjp": (ctypes.c_int, [_P, _P, _P, _I64, ctypes.c_float, _P, _P, _P, _P, _I64, _P]),
   "cnf_score_residual": (ctypes.c_int, [_P, _P, _I64, _I64, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_int32, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P]),
+  "cnf_term_residual": (ctypes.c_int, [ctypes.c_int32, _P, _P, _I64, _I64, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
+                                       ctypes.c_float, _P, _P, _P, _P]),
   "cnf_rkl_residual": (ctypes.c_int, [_P, _P, _I64, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_float, _P, _P, _P, _P]),
   "cnf_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float, ctypes.c_float,

@@ -151,10 +151,10 @@ def _neg_logprob_tables(ctx, samples, cond, coef):
   be = ctx.be
   c = be.slice_conds([cond])
   x, ildj = be.inverse_logdet(samples, c)
-  lp = ildj - 0.5 * (x * x).sum(1) - float(np.log(2.0 * np.pi))      # per sample in float32 (as the fused term), summed in float64
   # d(-sum lp) scaled by coef: lp_bar = -coef; x_bar = lp_bar * d base/dx = coef * x; ld_bar = -coef
-  be.pass_vjp(samples, c, x * float(coef), torch.full_like(ildj, -float(coef)), True, grad=ctx.grad, want_xbar=False)
-  return -lp.sum(dtype=torch.float64).reshape(1)
+  total, xbar, ldbar = be.term_residual(_capi.TERM_NEG_LOGPROB, x, ildj, x.shape[0], loss_coef=coef)
+  be.pass_vjp(samples, c, xbar, ldbar, True, grad=ctx.grad, want_xbar=False)
+  return total
 
 
 def _kinetic_tables(ctx, z, conds, count, dt, coef):
@@ -166,11 +166,8 @@ def _kinetic_tables(ctx, z, conds, count, dt, coef):
   c2 = be.slice_conds(np.concatenate([th - half, th + half]))
   z2 = z.repeat(2 * S, 1)
   r, _ = be.forward_logdet(z2, c2, want_logdet=False)
-  n = S * count
-  v = (r[n:] - r[:n]) * (1.0 / dt)
-  sums = (v * v).view(S, -1).sum(1, dtype=torch.float64)
-  g = v * (2.0 * float(coef) / dt)                         # d(coef * sum v^2) / d r2 = -d / d r1
-  be.pass_vjp(z2, c2, torch.cat([-g, g]), None, False, grad=ctx.grad, want_xbar=False)
+  sums, rbar, _ = be.term_residual(_capi.TERM_KINETIC, r, None, count, p0=dt, loss_coef=coef)
+  be.pass_vjp(z2, c2, rbar, None, False, grad=ctx.grad, want_xbar=False)
   return sums
 
 
@@ -182,20 +179,10 @@ def _potential_tables(ctx, z, conds, count, subtype, a, coef):
   c = be.slice_conds(th)
   zr = z.repeat(S, 1) if S > 1 else z
   r, _ = be.forward_logdet(zr, c, want_logdet=False)
-  s2 = (r * r).sum(1)
-  if subtype == "quadratic":                               # |r|^2 / 2
-    val, rbar = 0.5 * s2, r * float(coef)
-  elif subtype == "obstacle":                              # 50 exp(-|r|^2 / 2)
-    val = 50.0 * torch.exp(-0.5 * s2)
-    rbar = r * (val * -float(coef))[:, None]
-  elif subtype == "double_well":                           # (|r - a| |r + a| / 2)^2 = sm sp / 4
-    sm, sp = ((r - a) ** 2).sum(1), ((r + a) ** 2).sum(1)
-    val = 0.25 * sm * sp
-    rbar = (0.5 * float(coef)) * ((r - a) * sp[:, None] + (r + a) * sm[:, None])
-  else:
-    raise ValueError(f"unknown potential {subtype!r}")
-  be.pass_vjp(zr, c, rbar.contiguous(), None, False, grad=ctx.grad, want_xbar=False)
-  return val.view(S, -1).sum(1, dtype=torch.float64)
+  sums, rbar, _ = be.term_residual(_capi.TERM_POTENTIAL, r, None, count, subtype=_capi.POTENTIALS[subtype], p0=a,
+                                   loss_coef=coef)
+  be.pass_vjp(zr, c, rbar, None, False, grad=ctx.grad, want_xbar=False)
+  return sums
 
 
 def _kl_sum(ctx, T, cond, batch_size, source, coef):

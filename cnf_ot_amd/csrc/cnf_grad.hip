@@ -1083,6 +1083,91 @@ __global__ __launch_bounds__(256) void score_residual_kernel(const ResidArgs a) 
   }
 }
 
+// Value and adjoints of the terms cnf_ot_amd.applications composes from table launches at dim 2 (5.4b): one thread
+// per sample, per-slice sums like score_residual_kernel.
+//   CNF_TERM_KINETIC:      r = [r1 | r2] (2 n points), sums[s] = sum |(r2 - r1) / dt|^2, rbar = -+ 2 c (r2 - r1) / dt^2
+//   CNF_TERM_POTENTIAL:    r (n points), sums[s] = sum V(r), rbar = c grad V(r)            (CnfPotential subtype, a)
+//   CNF_TERM_NEG_LOGPROB:  r = recovered base points x, aux = ildj: sums[s] = -sum (base(x) + ildj), rbar = c x,
+//                          auxbar = -c
+struct TermResidArgs {
+  const float* r; const float* aux; float* rbar; float* auxbar; double* sums;
+  int64_t n, count;
+  int32_t kind, D, subtype;
+  float p0, loss_coef;
+};
+
+__global__ __launch_bounds__(256) void term_residual_kernel(const TermResidArgs a) {
+  const int D = a.D;
+  // A running per-lane sum of the CURRENT slice: a wave adds to sums[] only when
+  // its slice changes and once at the end -- one double atomic per wave and 64 samples (the first version) put
+  // 65 536 atomics on ONE address for a 4.2 M-sample slice and took longer than the flow kernels around it.
+  int64_t cur = -1;
+  float acc = 0.0f;
+  auto flush = [&]() {            // (wave-uniform call: every lane holds the same `cur` or -1)
+    float part = acc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    const int64_t s0 = __shfl(cur, 0, 64);
+    if ((threadIdx.x & 63) == 0 && s0 >= 0) unsafeAtomicAdd(a.sums + s0, (double)part);
+    acc = 0.0f;
+  };
+  // a workgroup owns a contiguous run of samples (a wave stays inside one slice for many iterations)
+  const int64_t per_block = ((a.n + gridDim.x - 1) / gridDim.x + 255) & ~(int64_t)255;
+  const int64_t b0 = blockIdx.x * per_block, b1 = b0 + per_block < a.n ? b0 + per_block : a.n;
+  for (int64_t base = b0; base < b1; base += 256) {
+    const int64_t i = base + threadIdx.x;
+    const bool valid = i < b1;
+    const int64_t slice = valid ? i / a.count : -1;
+    // lanes of a wave that straddle two slices: handled one by one (rare: only at slice borders)
+    const int64_t sl0 = __shfl(slice, 0, 64), sl63 = __shfl(slice, 63, 64);
+    const bool uniform = sl0 == sl63 && sl0 >= 0;
+    if (uniform && sl0 != cur) { if (cur >= 0) flush(); cur = sl0; }
+    float v = 0.0f;
+    if (valid) {
+      if (a.kind == CNF_TERM_KINETIC) {
+        const float inv_dt = 1.0f / a.p0, g = 2.0f * a.loss_coef * inv_dt * inv_dt;
+        for (int d = 0; d < D; ++d) {
+          const float dr = a.r[(a.n + i) * D + d] - a.r[i * D + d];
+          const float w = dr * inv_dt;
+          v = fmaf(w, w, v);
+          if (a.rbar) { a.rbar[i * D + d] = -g * dr; a.rbar[(a.n + i) * D + d] = g * dr; }
+        }
+      } else if (a.kind == CNF_TERM_POTENTIAL) {
+        float s2 = 0.0f, sm = 0.0f, sp = 0.0f;
+        for (int d = 0; d < D; ++d) {
+          const float x = a.r[i * D + d];
+          s2 = fmaf(x, x, s2); sm = fmaf(x - a.p0, x - a.p0, sm); sp = fmaf(x + a.p0, x + a.p0, sp);
+        }
+        if (a.subtype == CNF_POT_DOUBLE_WELL) v = 0.25f * sm * sp;            // (|r - a| |r + a| / 2)^2, applications.py:184-188
+        else if (a.subtype == CNF_POT_OBSTACLE) v = 50.0f * expf(-0.5f * s2);  // :190-191
+        else v = 0.5f * s2;                                                    // :181-182
+        if (a.rbar) {
+          for (int d = 0; d < D; ++d) {
+            const float x = a.r[i * D + d];
+            float gr;
+            if (a.subtype == CNF_POT_DOUBLE_WELL) gr = 0.5f * ((x - a.p0) * sp + (x + a.p0) * sm);
+            else if (a.subtype == CNF_POT_OBSTACLE) gr = -v * x;
+            else gr = x;
+            a.rbar[i * D + d] = a.loss_coef * gr;
+          }
+        }
+      } else {      // CNF_TERM_NEG_LOGPROB
+        float s2 = 0.0f;
+        for (int d = 0; d < D; ++d) {
+          const float x = a.r[i * D + d];
+          s2 = fmaf(x, x, s2);
+          if (a.rbar) a.rbar[i * D + d] = a.loss_coef * x;
+        }
+        v = -(a.aux[i] - 0.5f * s2 - (float)(D * HALF_LOG_2PI));
+        if (a.auxbar) a.auxbar[i] = -a.loss_coef;
+      }
+    }
+    if (uniform) acc += v;
+    else if (valid) unsafeAtomicAdd(a.sums + slice, (double)v);
+  }
+  if (cur >= 0) flush();
+}
+
 struct RklArgs {
   const float* y;        // [n, D] samples
   const float* lp;       // [n] their log_prob
@@ -1096,9 +1181,10 @@ struct RklArgs {
 
 // sum_i log_prob_i - log(N(y_i; 0, vs I) ws + N(y_i; 0, vt I) wt)  (reverse_kl_loss_fn, applications.py:129-163)
 __global__ __launch_bounds__(256) void rkl_residual_kernel(const RklArgs a) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  // grid-stride with a running per-lane sum: one double atomic per wave at the END (one per 64 samples put 65 536
+  // atomics on the single address of a 4 M-sample batch)
   float acc = 0.0f;
-  if (i < a.n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
     const int D = a.D;
     float s2 = 0.0f;
     for (int d = 0; d < D; ++d) { const float r = a.y[i * D + d]; s2 = fmaf(r, r, s2); }
@@ -1108,7 +1194,7 @@ __global__ __launch_bounds__(256) void rkl_residual_kernel(const RklArgs a) {
     const float as = -0.5f * s2 / vs + ls, at = -0.5f * s2 / vt + lt;
     const float mx = fmaxf(as, at);
     const float es = expf(as - mx) * ws, et = expf(at - mx) * wt;
-    acc = a.lp[i] - (mx + logf(es + et));
+    acc += a.lp[i] - (mx + logf(es + et));
     if (a.ybar) {
       const float g = (es / vs + et / vt) / (es + et);      // -d logmix / d y_e = g * y_e
       for (int d = 0; d < D; ++d) a.ybar[i * D + d] = a.loss_coef * g * a.y[i * D + d];
@@ -1118,7 +1204,7 @@ __global__ __launch_bounds__(256) void rkl_residual_kernel(const RklArgs a) {
   float part = acc;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-  if ((threadIdx.x & 63) == 0) atomicAdd(a.sums, (double)part);
+  if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(a.sums, (double)part);
 }
 
 }  // namespace cnf
@@ -1435,6 +1521,26 @@ extern "C" int cnf_score_residual(const float* r, const float* score, int64_t n,
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 
+extern "C" int cnf_term_residual(int32_t kind, const float* r, const float* aux, int64_t n, int64_t count, int32_t D,
+                                 int32_t subtype, float p0, float loss_coef, double* sums, float* rbar,
+                                 float* auxbar, void* stream_) {
+  if (!r || !sums || n < 0 || count < 1 || D < 1) return CNF_ERR_INVALID;
+  if (kind != CNF_TERM_KINETIC && kind != CNF_TERM_POTENTIAL && kind != CNF_TERM_NEG_LOGPROB) return CNF_ERR_INVALID;
+  if (kind == CNF_TERM_KINETIC && !(p0 > 0.f)) return CNF_ERR_INVALID;
+  if (kind == CNF_TERM_NEG_LOGPROB && !aux) return CNF_ERR_INVALID;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t n_slices = (n + count - 1) / count;
+  if (n_slices > 0 && hipMemsetAsync(sums, 0, sizeof(double) * (size_t)n_slices, stream) != hipSuccess) return CNF_ERR_HIP;
+  if (n == 0) return CNF_OK;
+  TermResidArgs a;
+  a.r = r; a.aux = aux; a.rbar = rbar; a.auxbar = auxbar; a.sums = sums; a.n = n; a.count = count;
+  a.kind = kind; a.D = D; a.subtype = subtype; a.p0 = p0; a.loss_coef = loss_coef;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(term_residual_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
 extern "C" int cnf_rkl_residual(const float* y, const float* lp, int64_t n, int32_t D, float t, float T, float beta,
                                 float loss_coef, double* sum, float* ybar, float* lpbar, void* stream_) {
   if (!y || !lp || !sum || n < 0 || D < 1 || !(T > 0.f) || !(beta > 0.f) || (ybar == nullptr) != (lpbar == nullptr))
@@ -1445,6 +1551,8 @@ extern "C" int cnf_rkl_residual(const float* y, const float* lp, int64_t n, int3
   RklArgs a;
   a.y = y; a.lp = lp; a.ybar = ybar; a.lpbar = lpbar; a.sums = sum; a.n = n; a.D = D;
   a.t = t; a.T = T; a.beta = beta; a.loss_coef = loss_coef;
-  hipLaunchKernelGGL(rkl_residual_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(rkl_residual_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }

@@ -448,6 +448,23 @@ class FlowEngine:
                                               _stream_ptr(self.device)), "cnf_score_residual")
     return sums, rbar, sbar
 
+  def term_residual(self, kind: int, r, aux, count: int, subtype: int = 0, p0: float = 0.0, loss_coef: float = 0.0,
+                    want_adjoints: bool = True):
+    """cnf_term_residual: per-slice sums (float64) of a kinetic / potential / density-fit term from the outputs of
+    its flow launches, and the adjoints (rbar, auxbar) of those outputs."""
+    n = r.shape[0] // (2 if kind == _capi.TERM_KINETIC else 1)
+    D = r.shape[1]
+    sums = torch.empty(-(-n // count), dtype=torch.float64, device=self.device)
+    rbar = torch.empty_like(r) if want_adjoints else None
+    auxbar = torch.empty_like(aux) if (want_adjoints and aux is not None) else None
+    with torch.cuda.device(self.device):
+      _capi.check(self.lib.cnf_term_residual(int(kind), r.data_ptr(), aux.data_ptr() if aux is not None else None, n,
+                                             int(count), D, int(subtype), float(p0), float(loss_coef), sums.data_ptr(),
+                                             rbar.data_ptr() if rbar is not None else None,
+                                             auxbar.data_ptr() if auxbar is not None else None,
+                                             _stream_ptr(self.device)), "cnf_term_residual")
+    return sums, rbar, auxbar
+
   def rkl_residual(self, y, lp, t: float, T: float, beta: float, loss_coef: float = 0.0, want_adjoints: bool = False):
     """cnf_rkl_residual: sum_i lp_i - log mixture(y_i) (float64 [1]); with want_adjoints also (ybar, lpbar)."""
     n, D = y.shape

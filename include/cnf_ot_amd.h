@@ -352,6 +352,15 @@ int cnf_logprob_fd_vjp(CnfModel *m, const float *pts, const float *c,
  * cnf_rkl_residual: y [n, D], lp [n] from cnf_sample_logprob;
  * sum = sum_i lp_i - log(mixture(y_i)) of reverse_kl_loss_fn
  * (applications.py:129-163), adjoints ybar / lpbar likewise. */
+/* cnf_term_residual: value and adjoints of the kinetic / potential / density-fit terms composed from separate flow
+ * launches (kinetic_loss_fn applications.py:220-242: r = [r1 | r2], 2 n points, p0 = dt; potential_loss_fn :176-205:
+ * r = n points, subtype = CnfPotential, p0 = a; kl_loss_fn :11-86: r = the recovered base points, aux = ildj).
+ * sums [ceil(n / count)] per slice; rbar (and auxbar for the density fit) receive loss_coef * d(sum) / d(.) when
+ * non-NULL. */
+int cnf_term_residual(int32_t kind, const float *r, const float *aux, int64_t n,
+                      int64_t count, int32_t D, int32_t subtype, float p0,
+                      float loss_coef, double *sums, float *rbar, float *auxbar,
+                      void *stream);
 int cnf_score_residual(const float *r, const float *score, int64_t n,
                        int64_t count, int32_t D, float dt, float coef,
                        int32_t drift, float a, float loss_coef, double *sums,
