@@ -1196,6 +1196,24 @@ __host__ __device__ inline int64_t cond_floats_p(int d, int H, int M, int P, boo
   return cond_floats_rows((periodic ? 2 : 1) * (1 + d), H, M, P);
 }
 
+// A wave's contribution to the per-slice sums of a loss kernel: the tiles' wave-reduced partial sums are added up
+// in a register while the wave stays in one slice, and go to sums[slice] with ONE double atomic when the slice
+// changes and at the end.  (One atomic per wave and tile put 65 536 of them on the single address of a 4.2 M-sample
+// slice -- a compare-and-swap loop each, without -munsafe-fp-atomics -- and cost more than the flow passes.)
+struct SliceSum {
+  double run = 0.0;
+  int64_t slice = -1;
+  __device__ __forceinline__ void flush(double* sums) {
+    if (slice >= 0 && (threadIdx.x & 63) == 0 && run != 0.0) unsafeAtomicAdd(sums + slice, run);
+    run = 0.0;
+  }
+  // s: the tile's slice (wave-uniform); part: the tile's sum over the wave's lanes (the same in every lane)
+  __device__ __forceinline__ void add(double* sums, int64_t s, float part) {
+    if (s != slice) { flush(sums); slice = s; }
+    run += (double)part;
+  }
+};
+
 // ---------------------------------------------------------------------------
 // Philox4x32-10 (same stream as oracle/cnf_oracle.c).
 // ---------------------------------------------------------------------------

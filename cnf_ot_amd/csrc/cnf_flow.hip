@@ -847,6 +847,7 @@ __global__ __launch_bounds__(TILE, 2) void loss_kernel(const LossArgs a) {
 
   const int64_t tiles_per_slice = (a.B + TS - 1) / TS;
   const int64_t n_tiles = tiles_per_slice * a.n_slices;
+  SliceSum ssum;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t slice = tile / tiles_per_slice;
     const int64_t tile_start = (tile - slice * tiles_per_slice) * TS;
@@ -920,12 +921,13 @@ __global__ __launch_bounds__(TILE, 2) void loss_kernel(const LossArgs a) {
         acc = vfma(v, v, acc);
       }
     }
-    // tile reduction: lanes -> wave (shuffles) -> one double atomic per wave
+    // tile reduction: lanes -> wave (shuffles) -> the wave's running sum of the slice
     float part = mask_tail(acc, i, a.B);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(a.sums + slice, (double)part);
+    ssum.add(a.sums, slice, part);
   }
+  ssum.flush(a.sums);
 }
 
 
@@ -980,6 +982,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void loss_pwl_kernel(const LossPwl
   const int t0 = blockIdx.x * per_block;
   const int t1 = t0 + per_block < total ? t0 + per_block : total;
   int cur = -1;
+  SliceSum ssum;
   for (int tile = t0; tile < t1; ++tile) {
     const int slice = tile / a.tiles_per_slice;
     __syncthreads();                                        // the previous tile is done with R (and the tables)
@@ -1070,12 +1073,13 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void loss_pwl_kernel(const LossPwl
         acc = vfma(v, v, acc);
       }
     }
-    // tile reduction: lanes -> wave (shuffles) -> one double atomic per wave
+    // tile reduction: lanes -> wave (shuffles) -> the wave's running sum of the slice
     float part = (v0 ? acc.x : 0.0f) + (v1 ? acc.y : 0.0f);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if ((tid & 63) == 0) atomicAdd(a.sums + slice, (double)part);
+    ssum.add(a.sums, slice, part);
   }
+  ssum.flush(a.sums);
 }
 
 // ---------------------------------------------------------------------------

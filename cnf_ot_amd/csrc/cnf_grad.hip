@@ -280,6 +280,7 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void grad_kernel(const
 
   const int64_t tiles_per_slice = (a.B + GTS - 1) / GTS;
   const int64_t n_tiles = tiles_per_slice * a.n_slices;
+  SliceSum ssum;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t slice = tile / tiles_per_slice;
     const int64_t tile_start = (tile - slice * tiles_per_slice) * GTS;
@@ -432,8 +433,9 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void grad_kernel(const
     float part = valid ? lossv : 0.0f;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if ((tid & 63) == 0) atomicAdd(a.sums + slice, (double)part);
+    ssum.add(a.sums, slice, part);
   }
+  ssum.flush(a.sums);
   // per-bin adjoint sums of the shared `first` spline: wave reduce, one owner write
   float red[GP];
 #pragma unroll
