@@ -634,7 +634,14 @@ __global__ __launch_bounds__(256) void adjoint_max_kernel(const float* __restric
   if (ldbar) scan(ldbar, n_l);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  __shared__ uint32_t wm[4];                 // one atomic per workgroup: they all land on one address
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t a01 = wm[0] > wm[1] ? wm[0] : wm[1], a23 = wm[2] > wm[3] ? wm[2] : wm[3];
+    const uint32_t mm = a01 > a23 ? a01 : a23;
+    if (mm) atomicMax(out, mm);
+  }
 }
 
 struct VjpPwlArgs {
@@ -1371,7 +1378,7 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     a.B = (B - first) < ns * slice_len ? (B - first) : ns * slice_len;
     a.slice_len = slice_len; a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps;
     if (hipMemsetAsync(amax, 0, 4, stream) != hipSuccess) return CNF_ERR_HIP;
-    hipLaunchKernelGGL(adjoint_max_kernel, dim3((unsigned)(m->num_cus * 4)), dim3(256), 0, stream, a.ybar, a.ybar ? 2 * a.B : 0, a.ldbar,
+    hipLaunchKernelGGL(adjoint_max_kernel, dim3((unsigned)(m->num_cus * 2)), dim3(256), 0, stream, a.ybar, a.ybar ? 2 * a.B : 0, a.ldbar,
                        a.ldbar ? a.B : 0, amax);
     const int64_t tiles = ns * tps;
     const int64_t grid = tiles < m->num_cus ? tiles : m->num_cus;
