@@ -126,9 +126,12 @@ __device__ __forceinline__ float table_spline_bwd(const float* tab, float v, flo
 // normalisation of cond_spline (same selection), returns the adjoint of the
 // spline input and writes theta_bar[3K+1].
 // ---------------------------------------------------------------------------
-template <int K, bool INV, bool FAST>
+// SLOPES_OUT: the two non-zero slope adjoints and their position instead of the 2K .. 3K entries of tb (which are
+// then left untouched): theta_bar[2K + kk] = sb0, theta_bar[2K + kk + 1] = sb1.
+template <int K, bool INV, bool FAST, bool SLOPES_OUT = false>
 __device__ __forceinline__ float cond_spline_bwd(const float (&th)[3 * K + 1], float v, float out, float o_bar,
-                                                 float l_bar, const SplineConsts& sc, float (&tb)[3 * K + 1]) {
+                                                 float l_bar, const SplineConsts& sc, float (&tb)[3 * K + 1],
+                                                 int* kk_out = nullptr, float* sb0 = nullptr, float* sb1 = nullptr) {
   using M = Math<FAST>;
   float mw = th[0], mh = th[K];
 #pragma unroll
@@ -176,8 +179,12 @@ __device__ __forceinline__ float cond_spline_bwd(const float (&th)[3 * K + 1], f
   // slopes: d = softplus(t + off) + m  =>  dd/dt = sigmoid(t + off)
   const float sg0 = 1.0f / (1.0f + M::exp(-(t0 + sc.sp_offset)));
   const float sg1 = 1.0f / (1.0f + M::exp(-(t1 + sc.sp_offset)));
+  if constexpr (SLOPES_OUT) {
+    *kk_out = kk; *sb0 = a.d0 * sg0; *sb1 = a.d1 * sg1;
+  } else {
 #pragma unroll
-  for (int j = 0; j <= K; ++j) tb[2 * K + j] = (j == kk ? a.d0 * sg0 : 0.0f) + (j == kk + 1 ? a.d1 * sg1 : 0.0f);
+    for (int j = 0; j <= K; ++j) tb[2 * K + j] = (j == kk ? a.d0 * sg0 : 0.0f) + (j == kk + 1 ? a.d1 * sg1 : 0.0f);
+  }
   return a.v;
 }
 

@@ -791,17 +791,23 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
             th[m2] = fmaf(row[m2], du, row[PWL_P + m2]) * LN2 - (m2 >= 2 * K ? sc.sp_offset : 0.0f);
           }
         }
+        // theta_bar: the 2K softmax entries in tb, the two non-zero slope entries (knots kk, kk + 1 of the selected
+        // bin) apart -- their accumulators and their rows' slopes are addressed with kk instead of six predicated
+        // copies of everything
         float tb[PWL_P];
-        const float ub_o = cond_spline_bwd<K, INV, true>(th, in_o[step], out_o[step], ob_o, ld_bar, sc, tb);
-        float ucond_bar = 0.0f;
+        int kk;
+        float sb0, sb1;
+        const float ub_o = cond_spline_bwd<K, INV, true, true>(th, in_o[step], out_o[step], ob_o, ld_bar, sc, tb, &kk, &sb0, &sb1);
+        const float* rowk = (p < WIN ? tl + PWL_OFF_PIECE + p * PWL_ROW : gl + PWL_OFF_PIECE + p * PWL_ROW) + 2 * K + kk;
+        float ucond_bar = fmaf(rowk[0] * LN2, sb0, rowk[1] * LN2 * sb1);
 #pragma unroll
-        for (int m2 = 0; m2 < PWL_P; ++m2) ucond_bar = fmaf(S[m2], tb[m2], ucond_bar);
+        for (int m2 = 0; m2 < 2 * K; ++m2) ucond_bar = fmaf(S[m2], tb[m2], ucond_bar);
 #ifndef CNF_VJP_PWL_NO_ATOMICS     /* experiment switch: what the accumulation costs */
         if (valid) {
 #pragma unroll
-          for (int m2 = 0; m2 < PWL_P; ++m2) {
-            if (tb[m2] != 0.0f) { accumulate(slice, l, p, m2, tb[m2]); accumulate(slice, l, p, PWL_P + m2, du * tb[m2]); }
-          }
+          for (int m2 = 0; m2 < 2 * K; ++m2) { accumulate(slice, l, p, m2, tb[m2]); accumulate(slice, l, p, PWL_P + m2, du * tb[m2]); }
+          accumulate(slice, l, p, 2 * K + kk, sb0);     accumulate(slice, l, p, PWL_P + 2 * K + kk, du * sb0);
+          accumulate(slice, l, p, 2 * K + kk + 1, sb1); accumulate(slice, l, p, PWL_P + 2 * K + kk + 1, du * sb1);
         }
 #endif
         float ub_f = 0.0f;
