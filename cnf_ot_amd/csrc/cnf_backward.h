@@ -25,19 +25,22 @@ struct BinPartials {
   float l_x, l_x0, l_bw, l_bh, l_d0, l_d1;
 };
 
+// FAST: v_rcp_f32 (1 ulp) for the six reciprocals instead of IEEE division (ten instructions each)
+template <bool FAST = false>
 __device__ __forceinline__ BinPartials rqs_partials(float x, float x0, float bw, float bh, float d0,
                                                     float d1, float lo, float hi) {
+  using M = Math<FAST>;
   BinPartials p;
-  const float ibw = 1.0f / bw;
+  const float ibw = M::rcp(bw);
   const float z = clip01((x - x0) * ibw);
   const float s = bh * ibw;
   const float q = z - z * z, qp = 1.0f - 2.0f * z, omz = 1.0f - z;
   const float st = d0 + d1 - 2.0f * s;
   const float Nn = fmaf(s * z, z, d0 * q);
   const float den = fmaf(st, q, s);
-  const float iden = 1.0f / den;
+  const float iden = M::rcp(den);
   const float A = fmaf(d1 * z, z, fmaf(2.0f * s, q, d0 * omz * omz));
-  const float iA = 1.0f / A;
+  const float iA = M::rcp(A);
   const float iden2 = iden * iden;
   p.f_x = s * s * A * iden2;
   const float f_s = bh * (z * z * den - Nn * (1.0f - 2.0f * q)) * iden2;
@@ -49,7 +52,7 @@ __device__ __forceinline__ BinPartials rqs_partials(float x, float x0, float bw,
   const float Az = 2.0f * (d1 * z + s * qp - d0 * omz);
   const float denz = st * qp;
   const float l_z = Az * iA - 2.0f * denz * iden;
-  const float l_s = 2.0f / s + 2.0f * q * iA - 2.0f * (1.0f - 2.0f * q) * iden;
+  const float l_s = 2.0f * M::rcp(s) + 2.0f * q * iA - 2.0f * (1.0f - 2.0f * q) * iden;
   p.l_x = l_z * ibw;
   p.l_x0 = -p.l_x;
   p.l_bw = -(l_z * z + l_s * s) * ibw;
@@ -57,10 +60,10 @@ __device__ __forceinline__ BinPartials rqs_partials(float x, float x0, float bw,
   p.l_d0 = omz * omz * iA - 2.0f * q * iden;
   p.l_d1 = z * z * iA - 2.0f * q * iden;
   if (x <= lo) {        // linear tail through (lo, lo) with slope d0 of bin 0
-    p = BinPartials{d0, 0.f, 0.f, 0.f, x - lo, 0.f, 0.f, 0.f, 0.f, 0.f, 1.0f / d0, 0.f};
+    p = BinPartials{d0, 0.f, 0.f, 0.f, x - lo, 0.f, 0.f, 0.f, 0.f, 0.f, M::rcp(d0), 0.f};
   }
   if (x >= hi) {        // linear tail through (hi, hi) with slope d1 of the last bin
-    p = BinPartials{d1, 0.f, 0.f, 0.f, 0.f, x - hi, 0.f, 0.f, 0.f, 0.f, 0.f, 1.0f / d1};
+    p = BinPartials{d1, 0.f, 0.f, 0.f, 0.f, x - hi, 0.f, 0.f, 0.f, 0.f, 0.f, M::rcp(d1)};
   }
   return p;
 }
@@ -71,7 +74,7 @@ __device__ __forceinline__ BinPartials rqs_partials(float x, float x0, float bw,
 // at x = out,  v_bar = (o_bar - l_bar l_x) / f_x,  p_bar = -(f_p v_bar + l_bar l_p).
 struct BinAdjoint { float v, x0, y0, bw, bh, d0, d1; };
 
-template <bool INV>
+template <bool INV, bool FAST = false>
 __device__ __forceinline__ BinAdjoint bin_adjoint(const BinPartials& p, float o_bar, float l_bar) {
   BinAdjoint a;
   if (!INV) {
@@ -83,7 +86,7 @@ __device__ __forceinline__ BinAdjoint bin_adjoint(const BinPartials& p, float o_
     a.d0 = o_bar * p.f_d0 + l_bar * p.l_d0;
     a.d1 = o_bar * p.f_d1 + l_bar * p.l_d1;
   } else {
-    a.v = (o_bar - l_bar * p.l_x) / p.f_x;
+    a.v = (o_bar - l_bar * p.l_x) * Math<FAST>::rcp(p.f_x);
     a.x0 = -(p.f_x0 * a.v + l_bar * p.l_x0);
     a.y0 = -a.v;
     a.bw = -(p.f_bw * a.v + l_bar * p.l_bw);
@@ -101,16 +104,16 @@ __device__ __forceinline__ BinAdjoint bin_adjoint(const BinPartials& p, float o_
 // Hb[j], Db[j] (adjoint of slope j);  grad_finish_kernel applies the Jacobians
 // once, in float64.
 // ---------------------------------------------------------------------------
-template <int K, bool INV>
+template <int K, bool INV, bool FAST = false>
 __device__ __forceinline__ float table_spline_bwd(const float* tab, float v, float out, float o_bar, float l_bar,
                                                   const SplineConsts& sc, float (&Wb)[K], float (&Hb)[K],
                                                   float (&Db)[K + 1]) {
   const float* pos = tab + tab_off(INV ? F_YK : F_XK, K);
   const int k = bin_of<K>(pos, v);
   const float x = INV ? out : v;
-  const BinPartials p = rqs_partials(x, gather<K>(tab, F_X0, k), gather<K>(tab, F_BW, k), gather<K>(tab, F_BH, k),
-                                     gather<K>(tab, F_D0, k), gather<K>(tab, F_D1, k), sc.lo, sc.hi);
-  const BinAdjoint a = bin_adjoint<INV>(p, o_bar, l_bar);
+  const BinPartials p = rqs_partials<FAST>(x, gather<K>(tab, F_X0, k), gather<K>(tab, F_BW, k), gather<K>(tab, F_BH, k),
+                                           gather<K>(tab, F_D0, k), gather<K>(tab, F_D1, k), sc.lo, sc.hi);
+  const BinAdjoint a = bin_adjoint<INV, FAST>(p, o_bar, l_bar);
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     Wb[j] += (j < k ? a.x0 : 0.0f) + (j == k ? a.bw : 0.0f);
@@ -143,7 +146,7 @@ __device__ __forceinline__ float cond_spline_bwd(const float (&th)[3 * K + 1], f
     pw[k] = M::exp(th[k] - mw); ph[k] = M::exp(th[K + k] - mh);
     sw += pw[k]; sh += ph[k];
   }
-  const float isw = 1.0f / sw, ish = 1.0f / sh;
+  const float isw = M::rcp(sw), ish = M::rcp(sh);
 #pragma unroll
   for (int k = 0; k < K; ++k) { pw[k] *= isw; ph[k] *= ish; }      // softmax probabilities
   float px = sc.lo, py = sc.lo;
@@ -164,8 +167,8 @@ __device__ __forceinline__ float cond_spline_bwd(const float (&th)[3 * K + 1], f
     kk += ge ? 1 : 0;
   }
   const float d0 = knot_slope<FAST, float>(t0, sc), d1 = knot_slope<FAST, float>(t1, sc);
-  const BinPartials p = rqs_partials(INV ? out : v, x0, bw, bh, d0, d1, sc.lo, sc.hi);
-  const BinAdjoint a = bin_adjoint<INV>(p, o_bar, l_bar);
+  const BinPartials p = rqs_partials<FAST>(INV ? out : v, x0, bw, bh, d0, d1, sc.lo, sc.hi);
+  const BinAdjoint a = bin_adjoint<INV, FAST>(p, o_bar, l_bar);
   // widths: w_j = span p_j + min_bin, x0 = lo + sum_{j<k} w_j, bw = w_k
   //   theta_bar_j = span p_j (wbar_j - sum_i wbar_i p_i)
   const float Sw = a.x0 * cumw + a.bw * pkw, Sh = a.y0 * cumh + a.bh * pkh;
@@ -177,8 +180,8 @@ __device__ __forceinline__ float cond_spline_bwd(const float (&th)[3 * K + 1], f
     tb[K + j] = sc.span_eff * ph[j] * (hb - Sh);
   }
   // slopes: d = softplus(t + off) + m  =>  dd/dt = sigmoid(t + off)
-  const float sg0 = 1.0f / (1.0f + M::exp(-(t0 + sc.sp_offset)));
-  const float sg1 = 1.0f / (1.0f + M::exp(-(t1 + sc.sp_offset)));
+  const float sg0 = M::rcp(1.0f + M::exp(-(t0 + sc.sp_offset)));
+  const float sg1 = M::rcp(1.0f + M::exp(-(t1 + sc.sp_offset)));
   if constexpr (SLOPES_OUT) {
     *kk_out = kk; *sb0 = a.d0 * sg0; *sb1 = a.d1 * sg1;
   } else {

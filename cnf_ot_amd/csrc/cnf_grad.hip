@@ -189,10 +189,10 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab,
       }
     }
     float vb0;
-    if (to_base) vb0 = table_spline_bwd<GK, false>(tab, cu[first_idx * GTS], co[first_idx * GTS], ao[first_idx * GTS],
-                                                   ld_bar, a.sc, fa.Wb, fa.Hb, fa.Db);
-    else vb0 = table_spline_bwd<GK, true>(tab, cu[first_idx * GTS], co[first_idx * GTS], ao[first_idx * GTS],
-                                          ld_bar, a.sc, fa.Wb, fa.Hb, fa.Db);
+    if (to_base) vb0 = table_spline_bwd<GK, false, FAST>(tab, cu[first_idx * GTS], co[first_idx * GTS], ao[first_idx * GTS],
+                                                         ld_bar, a.sc, fa.Wb, fa.Hb, fa.Db);
+    else vb0 = table_spline_bwd<GK, true, FAST>(tab, cu[first_idx * GTS], co[first_idx * GTS], ao[first_idx * GTS],
+                                                ld_bar, a.sc, fa.Wb, fa.Hb, fa.Db);
     au[first_idx * GTS] += vb0;
     float* t = Ao; Ao = Au; Au = t;
   }
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void vjp_kernel(const 
 // in  A = sum theta_bar  and  B = sum (u - u_ref) theta_bar  over the samples that land in the piece
 // (oracle/pwl_grad.py restates the algebra; checked against per-sample backprop to 1e-9).  Per sample that leaves:
 // the forward through the tables, the spline partials (cond_spline_bwd / table_spline_bwd as in the MLP kernels),
-// the input adjoint S . theta_bar from the row already in LDS, and 24 accumulations -- no MLP recompute and no
+// the input adjoint S . theta_bar from the row already in LDS, and 20 accumulations -- no MLP recompute and no
 // per-sample GEMM.  pwl_stats_finish_kernel turns the statistics into gradient slabs, once per piece.
 //   vjp_pwl_kernel: one sample per lane, 1024 threads; LDS = `first` table | L tables (PWL_LROWS-row window) |
 //   64-bit fixed-point accumulators [L][64 pieces][33] (A | B per piece).
@@ -803,16 +803,40 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
 #pragma unroll
         for (int m2 = 0; m2 < 2 * K; ++m2) ucond_bar = fmaf(S[m2], tb[m2], ucond_bar);
 #ifndef CNF_VJP_PWL_NO_ATOMICS     /* experiment switch: what the accumulation costs */
+        // The adjoints of a softmax group's logits sum to zero: the last width and the last height entry are not
+        // accumulated (pwl_stats_finish_kernel restores them as minus the sum of the other four) -- 20 atomic
+        // instructions per layer.  One range test per layer decides between the straight-line form (every term
+        // within the fine scale, the piece's accumulators in LDS) and the general one.
         if (valid) {
+          float big = fmaxf(fabsf(sb0), fabsf(sb1));
 #pragma unroll
-          for (int m2 = 0; m2 < 2 * K; ++m2) { accumulate(slice, l, p, m2, tb[m2]); accumulate(slice, l, p, PWL_P + m2, du * tb[m2]); }
-          accumulate(slice, l, p, 2 * K + kk, sb0);     accumulate(slice, l, p, PWL_P + 2 * K + kk, du * sb0);
-          accumulate(slice, l, p, 2 * K + kk + 1, sb1); accumulate(slice, l, p, PWL_P + 2 * K + kk + 1, du * sb1);
+          for (int m2 = 0; m2 < 2 * K; ++m2) big = fmaxf(big, fabsf(tb[m2]));
+          big *= fmaxf(1.0f, fabsf(du));
+          if (p < PWL_ACC_W && (double)big * fx_scale < 1125899906842624.0) {
+            typedef stat_t __attribute__((address_space(3))) * lds_q_ptr;
+            lds_q_ptr d3 = (lds_q_ptr)(uintptr_t)(uint32_t)(uintptr_t)(acc + (l * PWL_ACC_W + p) * PWL_STAT_LDS);
+            auto add = [&](int e, float x) {
+              const double d = fma((double)x, fx_scale, 6755399441055744.0);
+              __hip_atomic_fetch_add(d3 + e, (stat_t)(__double_as_longlong(d) - __double_as_longlong(6755399441055744.0)),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+#pragma unroll
+            for (int m2 = 0; m2 < 2 * K; ++m2)
+              if (m2 % K != K - 1) { add(m2, tb[m2]); add(PWL_P + m2, du * tb[m2]); }
+            add(2 * K + kk, sb0);     add(PWL_P + 2 * K + kk, du * sb0);
+            add(2 * K + kk + 1, sb1); add(PWL_P + 2 * K + kk + 1, du * sb1);
+          } else {
+#pragma unroll
+            for (int m2 = 0; m2 < 2 * K; ++m2)
+              if (m2 % K != K - 1) { accumulate(slice, l, p, m2, tb[m2]); accumulate(slice, l, p, PWL_P + m2, du * tb[m2]); }
+            accumulate(slice, l, p, 2 * K + kk, sb0);     accumulate(slice, l, p, PWL_P + 2 * K + kk, du * sb0);
+            accumulate(slice, l, p, 2 * K + kk + 1, sb1); accumulate(slice, l, p, PWL_P + 2 * K + kk + 1, du * sb1);
+          }
         }
 #endif
         float ub_f = 0.0f;
         if (TO_BASE) ob_f += ucond_bar; else ub_f = ucond_bar;
-        ub_f += table_spline_bwd<K, INV>(tab, in_f[step], out_f[step], ob_f, ld_bar, sc, fa.Wb, fa.Hb, fa.Db);
+        ub_f += table_spline_bwd<K, INV, true>(tab, in_f[step], out_f[step], ob_f, ld_bar, sc, fa.Wb, fa.Hb, fa.Db);
         ob[odd ? 1 : 0] = ub_f; ob[odd ? 0 : 1] = ub_o;
       }
     }
@@ -889,6 +913,12 @@ __global__ __launch_bounds__(256) void pwl_stats_finish_kernel(const StatsFinish
     stat[i] = (float)(((double)(long long)q + (double)(long long)qc * 4294967296.0) * inv_scale);
     if (q != 0) st[i] = 0;                                 // cleared for the next call
     if (qc != 0) sc2[i] = 0;
+  }
+  __syncthreads();
+  // vjp_pwl_kernel leaves out the last logit of each softmax group (widths, heights): the group's adjoints sum to zero
+  for (int i = tid; i < (n + 1) * 4; i += blockDim.x) {
+    float* g = stat + (i >> 2) * PWL_STAT + (i & 2 ? P : 0) + (i & 1 ? GK : 0);
+    g[GK - 1] = -((g[0] + g[1]) + (g[2] + g[3]));
   }
   __syncthreads();
   float out[PER_LANE];
