@@ -1142,101 +1142,126 @@ struct TermResidArgs {
 };
 
 // DFIX = 2: the points are float2 -- one 8-byte load / store per point instead of a strided loop.
-// One thread per sample (the kernel is a stream of independent 8-byte accesses: it needs every wave it can get),
-// 1 024-thread workgroups; the sums go lanes -> wave (shuffles) -> workgroup (LDS) -> ONE double atomic per run of
-// equal slices in the workgroup.  (One atomic per wave put 65 536 of them on the single address of a 4.2 M-sample
-// slice and took longer than the flow kernels around it.)
+// The kernel is a stream of independent 8-byte accesses: 1 024-thread workgroups, RESID_PER points per thread a
+// workgroup-width apart (one point per thread left the chip waiting on workgroup launches: 49 us for 4.2 M points,
+// twice the time of the memory traffic).  The sums: a lane adds up its points of the wave's current slice; when the
+// slice changes the wave flushes (shuffles + one double atomic); at the end lanes -> wave -> workgroup (LDS) -> ONE
+// atomic per run of equal slices in the workgroup.  (One atomic per wave put 65 536 of them on the single address of
+// a 4.2 M-sample slice and took longer than the flow kernels around it.)
+constexpr int RESID_PER = 4;
 template <int DFIX>
 __global__ __launch_bounds__(1024) void term_residual_kernel(const TermResidArgs a) {
   const int D = DFIX ? DFIX : a.D;
   __shared__ double wsum[16];
   __shared__ long long wslice[16];
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const bool valid = i < a.n;
-  float v = 0.0f;
-  if (valid && DFIX == 2) {
-    const v2f* r2p = reinterpret_cast<const v2f*>(a.r);
-    v2f* rb2 = reinterpret_cast<v2f*>(a.rbar);
-    if (a.kind == CNF_TERM_KINETIC) {
-      const float inv_dt = 1.0f / a.p0, g = 2.0f * a.loss_coef * inv_dt * inv_dt;
-      const v2f dr = r2p[a.n + i] - r2p[i];
-      const v2f w = dr * inv_dt;
-      v = fmaf(w.x, w.x, w.y * w.y);
-      if (a.rbar) { rb2[i] = dr * -g; rb2[a.n + i] = dr * g; }
-    } else if (a.kind == CNF_TERM_POTENTIAL) {
-      const v2f x = r2p[i];
-      const float s2 = fmaf(x.x, x.x, x.y * x.y);
-      const v2f xm = x - a.p0, xp = x + a.p0;
-      const float sm = fmaf(xm.x, xm.x, xm.y * xm.y), sp = fmaf(xp.x, xp.x, xp.y * xp.y);
-      v2f gr;
-      if (a.subtype == CNF_POT_DOUBLE_WELL) { v = 0.25f * sm * sp; gr = (xm * sp + xp * sm) * 0.5f; }      // applications.py:184-188
-      else if (a.subtype == CNF_POT_OBSTACLE) { v = 50.0f * expf(-0.5f * s2); gr = x * -v; }                // :190-191
-      else { v = 0.5f * s2; gr = x; }                                                                        // :181-182
-      if (a.rbar) rb2[i] = gr * a.loss_coef;
-    } else {      // CNF_TERM_NEG_LOGPROB
-      const v2f x = r2p[i];
-      if (a.rbar) rb2[i] = x * a.loss_coef;
-      v = -(a.aux[i] - 0.5f * fmaf(x.x, x.x, x.y * x.y) - (float)(2 * HALF_LOG_2PI));
-      if (a.auxbar) a.auxbar[i] = -a.loss_coef;
-    }
-  } else if (valid) {
-    if (a.kind == CNF_TERM_KINETIC) {
-      const float inv_dt = 1.0f / a.p0, g = 2.0f * a.loss_coef * inv_dt * inv_dt;
-      for (int d = 0; d < D; ++d) {
-        const float dr = a.r[(a.n + i) * D + d] - a.r[i * D + d];
-        const float w = dr * inv_dt;
-        v = fmaf(w, w, v);
-        if (a.rbar) { a.rbar[i * D + d] = -g * dr; a.rbar[(a.n + i) * D + d] = g * dr; }
-      }
-    } else if (a.kind == CNF_TERM_POTENTIAL) {
-      float s2 = 0.0f, sm = 0.0f, sp = 0.0f;
-      for (int d = 0; d < D; ++d) {
-        const float x = a.r[i * D + d];
-        s2 = fmaf(x, x, s2); sm = fmaf(x - a.p0, x - a.p0, sm); sp = fmaf(x + a.p0, x + a.p0, sp);
-      }
-      if (a.subtype == CNF_POT_DOUBLE_WELL) v = 0.25f * sm * sp;
-      else if (a.subtype == CNF_POT_OBSTACLE) v = 50.0f * expf(-0.5f * s2);
-      else v = 0.5f * s2;
-      if (a.rbar) {
-        for (int d = 0; d < D; ++d) {
-          const float x = a.r[i * D + d];
-          float gr;
-          if (a.subtype == CNF_POT_DOUBLE_WELL) gr = 0.5f * ((x - a.p0) * sp + (x + a.p0) * sm);
-          else if (a.subtype == CNF_POT_OBSTACLE) gr = -v * x;
-          else gr = x;
-          a.rbar[i * D + d] = a.loss_coef * gr;
-        }
+  auto term = [&](int64_t i) -> float {      // the term's value at point i; writes the adjoints
+    float v = 0.0f;
+    if (DFIX == 2) {
+      const v2f* r2p = reinterpret_cast<const v2f*>(a.r);
+      v2f* rb2 = reinterpret_cast<v2f*>(a.rbar);
+      if (a.kind == CNF_TERM_KINETIC) {
+        const float inv_dt = 1.0f / a.p0, g = 2.0f * a.loss_coef * inv_dt * inv_dt;
+        const v2f dr = r2p[a.n + i] - r2p[i];
+        const v2f w = dr * inv_dt;
+        v = fmaf(w.x, w.x, w.y * w.y);
+        if (a.rbar) { rb2[i] = dr * -g; rb2[a.n + i] = dr * g; }
+      } else if (a.kind == CNF_TERM_POTENTIAL) {
+        const v2f x = r2p[i];
+        const float s2 = fmaf(x.x, x.x, x.y * x.y);
+        const v2f xm = x - a.p0, xp = x + a.p0;
+        const float sm = fmaf(xm.x, xm.x, xm.y * xm.y), sp = fmaf(xp.x, xp.x, xp.y * xp.y);
+        v2f gr;
+        if (a.subtype == CNF_POT_DOUBLE_WELL) { v = 0.25f * sm * sp; gr = (xm * sp + xp * sm) * 0.5f; }      // applications.py:184-188
+        else if (a.subtype == CNF_POT_OBSTACLE) { v = 50.0f * expf(-0.5f * s2); gr = x * -v; }                // :190-191
+        else { v = 0.5f * s2; gr = x; }                                                                        // :181-182
+        if (a.rbar) rb2[i] = gr * a.loss_coef;
+      } else {      // CNF_TERM_NEG_LOGPROB
+        const v2f x = r2p[i];
+        if (a.rbar) rb2[i] = x * a.loss_coef;
+        v = -(a.aux[i] - 0.5f * fmaf(x.x, x.x, x.y * x.y) - (float)(2 * HALF_LOG_2PI));
+        if (a.auxbar) a.auxbar[i] = -a.loss_coef;
       }
     } else {
-      float s2 = 0.0f;
-      for (int d = 0; d < D; ++d) {
-        const float x = a.r[i * D + d];
-        s2 = fmaf(x, x, s2);
-        if (a.rbar) a.rbar[i * D + d] = a.loss_coef * x;
+      if (a.kind == CNF_TERM_KINETIC) {
+        const float inv_dt = 1.0f / a.p0, g = 2.0f * a.loss_coef * inv_dt * inv_dt;
+        for (int d = 0; d < D; ++d) {
+          const float dr = a.r[(a.n + i) * D + d] - a.r[i * D + d];
+          const float w = dr * inv_dt;
+          v = fmaf(w, w, v);
+          if (a.rbar) { a.rbar[i * D + d] = -g * dr; a.rbar[(a.n + i) * D + d] = g * dr; }
+        }
+      } else if (a.kind == CNF_TERM_POTENTIAL) {
+        float s2 = 0.0f, sm = 0.0f, sp = 0.0f;
+        for (int d = 0; d < D; ++d) {
+          const float x = a.r[i * D + d];
+          s2 = fmaf(x, x, s2); sm = fmaf(x - a.p0, x - a.p0, sm); sp = fmaf(x + a.p0, x + a.p0, sp);
+        }
+        if (a.subtype == CNF_POT_DOUBLE_WELL) v = 0.25f * sm * sp;
+        else if (a.subtype == CNF_POT_OBSTACLE) v = 50.0f * expf(-0.5f * s2);
+        else v = 0.5f * s2;
+        if (a.rbar) {
+          for (int d = 0; d < D; ++d) {
+            const float x = a.r[i * D + d];
+            float gr;
+            if (a.subtype == CNF_POT_DOUBLE_WELL) gr = 0.5f * ((x - a.p0) * sp + (x + a.p0) * sm);
+            else if (a.subtype == CNF_POT_OBSTACLE) gr = -v * x;
+            else gr = x;
+            a.rbar[i * D + d] = a.loss_coef * gr;
+          }
+        }
+      } else {
+        float s2 = 0.0f;
+        for (int d = 0; d < D; ++d) {
+          const float x = a.r[i * D + d];
+          s2 = fmaf(x, x, s2);
+          if (a.rbar) a.rbar[i * D + d] = a.loss_coef * x;
+        }
+        v = -(a.aux[i] - 0.5f * s2 - (float)(D * HALF_LOG_2PI));
+        if (a.auxbar) a.auxbar[i] = -a.loss_coef;
       }
-      v = -(a.aux[i] - 0.5f * s2 - (float)(D * HALF_LOG_2PI));
-      if (a.auxbar) a.auxbar[i] = -a.loss_coef;
+    }
+    return v;
+  };
+  auto wave_sum = [](float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+  };
+  const bool small = a.n < ((int64_t)1 << 31) && a.count < ((int64_t)1 << 31);      // 32-bit slice arithmetic
+  const int64_t base = blockIdx.x * (int64_t)(blockDim.x * RESID_PER) + threadIdx.x;
+  float acc = 0.0f;              // this lane's points of slice `cur`
+  long long cur = -1;            // wave-uniform
+#pragma unroll
+  for (int it = 0; it < RESID_PER; ++it) {
+    const int64_t i = base + (int64_t)it * blockDim.x;
+    const bool valid = i < a.n;
+    const float v = valid ? term(i) : 0.0f;
+    const long long slice = !valid ? -1 : small ? (long long)((uint32_t)i / (uint32_t)a.count) : (long long)(i / a.count);
+    const long long sl0 = __shfl(slice, 0, 64), sl63 = __shfl(slice, 63, 64);
+    if (sl0 == sl63) {                      // (-1 == -1: a wave past the end, contributing nothing)
+      if (sl0 != cur) {
+        const float part = wave_sum(acc);
+        if (cur >= 0 && (threadIdx.x & 63) == 0) unsafeAtomicAdd(a.sums + cur, (double)part);
+        cur = sl0; acc = 0.0f;
+      }
+      acc += v;
+    } else if (valid) {
+      unsafeAtomicAdd(a.sums + slice, (double)v);      // a wave across a slice border: per lane
     }
   }
-  const int64_t slice = valid ? i / a.count : -1;
-  const int64_t sl0 = __shfl(slice, 0, 64), sl63 = __shfl(slice, 63, 64);
-  const bool uniform = sl0 == sl63;                 // (-1 == -1: a wave past the end, contributing nothing)
-  float part = uniform ? v : 0.0f;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-  if (!uniform && valid) unsafeAtomicAdd(a.sums + slice, (double)v);      // a wave across a slice border: per lane
+  const float part = wave_sum(acc);
   const int wv = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { wsum[wv] = (double)part; wslice[wv] = uniform ? sl0 : -1; }
+  if ((threadIdx.x & 63) == 0) { wsum[wv] = (double)part; wslice[wv] = cur; }
   __syncthreads();
   if (threadIdx.x == 0) {
     const int nw = blockDim.x >> 6;
     double run = 0.0;
-    long long cur = -1;
+    long long c2 = -1;
     for (int w2 = 0; w2 < nw; ++w2) {
-      if (wslice[w2] != cur) { if (cur >= 0) unsafeAtomicAdd(a.sums + cur, run); cur = wslice[w2]; run = 0.0; }
+      if (wslice[w2] != c2) { if (c2 >= 0) unsafeAtomicAdd(a.sums + c2, run); c2 = wslice[w2]; run = 0.0; }
       run += wsum[w2];
     }
-    if (cur >= 0) unsafeAtomicAdd(a.sums + cur, run);
+    if (c2 >= 0) unsafeAtomicAdd(a.sums + c2, run);
   }
 }
 
@@ -1607,7 +1632,7 @@ extern "C" int cnf_term_residual(int32_t kind, const float* r, const float* aux,
   TermResidArgs a;
   a.r = r; a.aux = aux; a.rbar = rbar; a.auxbar = auxbar; a.sums = sums; a.n = n; a.count = count;
   a.kind = kind; a.D = D; a.subtype = subtype; a.p0 = p0; a.loss_coef = loss_coef;
-  const int64_t blocks = (n + 1023) / 1024;
+  const int64_t blocks = (n + 1024 * cnf::RESID_PER - 1) / (1024 * cnf::RESID_PER);
   const bool vec2 = D == 2 && (reinterpret_cast<uintptr_t>(r) & 7) == 0 && (reinterpret_cast<uintptr_t>(rbar) & 7) == 0;
   if (vec2) hipLaunchKernelGGL(term_residual_kernel<2>, dim3((unsigned)blocks), dim3(1024), 0, stream, a);
   else hipLaunchKernelGGL(term_residual_kernel<0>, dim3((unsigned)blocks), dim3(1024), 0, stream, a);

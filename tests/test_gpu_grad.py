@@ -397,3 +397,56 @@ def test_value_and_grad_through_the_table_backward(dev, subtype, monkeypatch):
   eg = (g2.flat - g0.flat).abs().max().item() / g0.flat.abs().max().item()
   print(f"\n[ot {subtype}: table backward vs fused kernel] loss rel {el:.2e} grad rel {eg:.2e}")
   assert el <= 2e-5 and eg <= 2e-4
+
+
+@pytest.mark.parametrize("D", [2, 3])
+@pytest.mark.parametrize("n,count", [(10000, 10000), (9999, 1234), (70001, 4096), (5000, 1), (300000, 131072)])
+def test_term_residual_sums_and_adjoints(dev, D, n, count):
+  """cnf_term_residual (the epilogue of the table-backward terms: applications.py:176-205, 220-242, 85) against a
+  float64 torch restatement: per-slice sums to 2e-6 relative, adjoints to float32 rounding.  Slices that end inside
+  a wave, inside a workgroup's four-point stride and past the last workgroup are all in the cases."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params, _capi
+  cfg = FlowConfig(dim=D)
+  eng = FlowEngine(cfg, dev).load(Params.random(cfg, 0.1, seed=1, device=dev))
+  g = torch.Generator(device="cpu").manual_seed(n + D)
+  n_slices = -(-n // count)
+  coef = 0.37
+
+  def slice_sums(v):
+    pad = torch.zeros(n_slices * count, dtype=torch.float64)
+    pad[:n] = v
+    return pad.view(n_slices, count).sum(1)
+
+  def check(sums, want):
+    # (the values are float32 per point: a one-point slice carries that rounding, relative to the term's scale)
+    torch.testing.assert_close(sums.cpu(), want, rtol=2e-6, atol=2e-6 * float(want.abs().max()) / min(count, 100))
+
+  # kinetic: r = [r1; r2], v = (r2 - r1) / dt
+  r = (torch.randn(2 * n, D, generator=g) * 1.5).to(dev)
+  dt = 0.01
+  sums, rbar, _ = eng.term_residual(_capi.TERM_KINETIC, r, None, count, p0=dt, loss_coef=coef)
+  r64 = r.cpu().double()
+  dr = r64[n:] - r64[:n]
+  check(sums, slice_sums(((dr / dt) ** 2).sum(1)))
+  gref = 2 * coef * dr / dt ** 2
+  torch.testing.assert_close(rbar.cpu().double(), torch.cat([-gref, gref]), rtol=2e-6, atol=1e-6)
+  # potentials
+  x = (torch.randn(n, D, generator=g) * 1.2).to(dev)
+  x64 = x.cpu().double()
+  for name, sub in _capi.POTENTIALS.items():
+    p0 = 1.5 if name == "double_well" else 0.0
+    sums, xbar, _ = eng.term_residual(_capi.TERM_POTENTIAL, x, None, count, subtype=sub, p0=p0, loss_coef=coef)
+    xr = x64.clone().requires_grad_(True)
+    if name == "double_well": v = 0.25 * ((xr - p0) ** 2).sum(1) * ((xr + p0) ** 2).sum(1)
+    elif name == "obstacle": v = 50.0 * torch.exp(-0.5 * (xr ** 2).sum(1))
+    else: v = 0.5 * (xr ** 2).sum(1)
+    check(sums, slice_sums(v.detach()))
+    (coef * v.sum()).backward()
+    torch.testing.assert_close(xbar.cpu().double(), xr.grad, rtol=5e-6, atol=1e-5)
+  # density fit: -(ld + base log-density of y)
+  ld = torch.randn(n, generator=g).to(dev)
+  sums, ybar, ldbar = eng.term_residual(_capi.TERM_NEG_LOGPROB, x, ld, count, loss_coef=coef)
+  v = -(ld.cpu().double() - 0.5 * (x64 ** 2).sum(1) - 0.5 * D * np.log(2 * np.pi))
+  check(sums, slice_sums(v))
+  torch.testing.assert_close(ybar.cpu().double(), coef * x64, rtol=1e-6, atol=1e-7)
+  assert torch.all(ldbar == -coef)
