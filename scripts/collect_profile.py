@@ -20,6 +20,9 @@ def main(tag):
   stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
   if stats:
     shutil.copy(stats[0], os.path.join(dst, "kernel_stats.csv"))
+  stats = glob.glob(os.path.join(src, "trace_metric", "*", "*_kernel_stats.csv"))
+  if stats:
+    shutil.copy(stats[0], os.path.join(dst, "kernel_stats_metric_only.csv"))
   if os.path.exists(os.path.join(src, "bench_line.json")):
     shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, "bench_line.json"))
   out = {}
