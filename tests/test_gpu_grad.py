@@ -450,3 +450,39 @@ def test_term_residual_sums_and_adjoints(dev, D, n, count):
   check(sums, slice_sums(v))
   torch.testing.assert_close(ybar.cpu().double(), coef * x64, rtol=1e-6, atol=1e-7)
   assert torch.all(ldbar == -coef)
+
+
+@pytest.mark.parametrize("to_base", [False, True])
+def test_table_backward_properties_at_config5_size(dev, to_base):
+  """The table backward at config 5's per-GPU share (32 slices x 131 072 points), through properties that need no
+  oracle at that size: (a) the same bits on a second call; (b) adjoints scaled by a power of two scale the
+  fixed-point statistics' scale with them, so gradient and input adjoints scale EXACTLY; (c) the gradient is a sum
+  over slices: the two halves of the time batch add up to the whole (float sums in another order: 2e-6)."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  cfg = FlowConfig(dim=2)
+  eng = FlowEngine(cfg, dev).load(Params.random(cfg, 0.2, seed=11, device=dev))
+  eng.set_pwl(2)
+  S, Bs = 32, 131072
+  B = S * Bs
+  gen = torch.Generator(device=dev).manual_seed(7)
+  pts = torch.randn(B, 2, generator=gen, device=dev) * 1.3
+  ybar = torch.randn(B, 2, generator=gen, device=dev)
+  ldbar = torch.randn(B, generator=gen, device=dev)
+  ts = torch.linspace(0.02, 0.98, S, device=dev)
+
+  def run(lo, hi, scale=1.0):
+    g = torch.zeros(cfg.param_count(), device=dev)
+    sl = slice(lo * Bs, hi * Bs)
+    xb = eng.pass_vjp(pts[sl], ts[lo:hi].contiguous(), ybar[sl] * scale, ldbar[sl] * scale, to_base, grad=g)
+    assert eng.last_path() == "tables"
+    return xb, g
+
+  xb, g = run(0, S)
+  xb2, g2 = run(0, S)
+  assert torch.equal(g, g2) and torch.equal(xb, xb2)
+  xb4, g4 = run(0, S, 4.0)
+  assert torch.equal(g4, g * 4.0) and torch.equal(xb4, xb * 4.0)
+  _, ga = run(0, S // 2)
+  _, gb = run(S // 2, S)
+  assert ((ga + gb) - g).abs().max().item() <= 2e-6 * g.abs().max().item()
+  assert torch.isfinite(g).all() and g.abs().max().item() > 0
