@@ -131,10 +131,16 @@ __device__ __forceinline__ float table_spline_bwd(const float* tab, float v, flo
 // ---------------------------------------------------------------------------
 // SLOPES_OUT: the two non-zero slope adjoints and their position instead of the 2K .. 3K entries of tb (which are
 // then left untouched): theta_bar[2K + kk] = sb0, theta_bar[2K + kk + 1] = sb1.
+// form_out (INV only, wave-uniform): `out` is not taken from the caller -- the inverse map is evaluated here, in the bin
+// this function has selected, on ITS knots.  The backward kernels all ask for it: the forward pass normalises the
+// softmax in another order, so next to a knot its output can lie a rounding outside the bin selected here, the
+// position clips to 0 or 1 and the implicit-function quotient 1 / f' is garbage (found by the table-backward soak:
+// both kernels 3e9 off the float64 oracle on two samples of 36 000, profiles/r02_experiments/soak_vjp_case_1_16.log).
 template <int K, bool INV, bool FAST, bool SLOPES_OUT = false>
 __device__ __forceinline__ float cond_spline_bwd(const float (&th)[3 * K + 1], float v, float out, float o_bar,
                                                  float l_bar, const SplineConsts& sc, float (&tb)[3 * K + 1],
-                                                 int* kk_out = nullptr, float* sb0 = nullptr, float* sb1 = nullptr) {
+                                                 int* kk_out = nullptr, float* sb0 = nullptr, float* sb1 = nullptr,
+                                                 bool form_out = false) {
   using M = Math<FAST>;
   float mw = th[0], mh = th[K];
 #pragma unroll
@@ -167,6 +173,16 @@ __device__ __forceinline__ float cond_spline_bwd(const float (&th)[3 * K + 1], f
     kk += ge ? 1 : 0;
   }
   const float d0 = knot_slope<FAST, float>(t0, sc), d1 = knot_slope<FAST, float>(t1, sc);
+  if (INV && form_out) {      // rqs_bin_eval's inverse branch and cond_spline's linear tails
+    const float sl = bh * M::rcp(bw), st = d0 + d1 - 2.0f * sl;
+    const float dy = fminf(fmaxf(v - y0, 0.0f), bh);
+    const float c = -sl * dy, b = fmaf(-st, dy, d0 * bh), a2 = fmaf(sl, bh, -b);
+    const float disc = fmaf(b, b, a2 * c * -4.0f);
+    const float z = clip01(M::div(c * -2.0f, b + M::sqrt(disc)));
+    out = fmaf(bw, z, x0);
+    if (v <= sc.lo) out = fmaf(v - sc.lo, M::rcp(d0), sc.lo);
+    if (v >= sc.hi) out = fmaf(v - sc.hi, M::rcp(d1), sc.hi);
+  }
   const BinPartials p = rqs_partials<FAST>(INV ? out : v, x0, bw, bh, d0, d1, sc.lo, sc.hi);
   const BinAdjoint a = bin_adjoint<INV, FAST>(p, o_bar, l_bar);
   // widths: w_j = span p_j + min_bin, x0 = lo + sum_{j<k} w_j, bw = w_k

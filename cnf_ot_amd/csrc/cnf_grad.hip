@@ -172,7 +172,10 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab,
         if constexpr (WGRAD) pre = wgrad_prefetch(gw, d);
         float vb;
         if (to_base) vb = cond_spline_bwd<GK, false, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
-        else vb = cond_spline_bwd<GK, true, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
+        // (base -> data: the output is formed again inside, in the bin the backward selects -- next to a knot the stashed
+        // one can lie a rounding outside that bin, and 1 / f' of a clipped position is garbage: soak_vjp_case_1_16.log)
+        else vb = cond_spline_bwd<GK, true, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb, nullptr, nullptr,
+                                                  nullptr, true);
         au[i * GTS] += vb;
         conditioner_bwd_mfma<WGRAD>(a.prep + hdr_floats(GK) + l * a.per_layer + off, w, d, c, to_base ? co : cu,
                                     first_idx, idx_step, GTS, mask1, h2m, tb, to_base ? ao : au, gw, stage, pre);
@@ -182,7 +185,8 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab,
         conditioner_keep(w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, h1, h2, th);
         float vb;
         if (to_base) vb = cond_spline_bwd<GK, false, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
-        else vb = cond_spline_bwd<GK, true, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
+        else vb = cond_spline_bwd<GK, true, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb, nullptr, nullptr,
+                                                  nullptr, true);
         au[i * GTS] += vb;
         conditioner_bwd<WGRAD>(w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, h1, h2, tb, to_base ? ao : au,
                                gw, stage ? stage + 16 * STG : nullptr, pre);
@@ -746,24 +750,30 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
     }
     const float* gtbl = a.tables + (int64_t)slice * L * PWL_TBL;
     // ---- forward through the tables, keeping every layer's inputs and outputs
-    float in_f[MAXL], in_o[MAXL], out_f[MAXL], out_o[MAXL];
+    float in_f[MAXL], in_o[MAXL], out_f[MAXL];
 #pragma unroll
     for (int step = 0; step < MAXL; ++step) {
       if (step < L) {
         const int l = TO_BASE ? L - 1 - step : step;
         const bool odd = l & 1;
         const float uf = odd ? u[1] : u[0], uo = odd ? u[0] : u[1];
-        float of, oo, ld;
+        float of, oo = 0.0f, ld;
         table_spline<K, INV, true, float>(tab, uf, sc, of, ld);
-        float th[PWL_P];
-        bool general;
-        pwl_eval<WIN>(tbl + l * pwl_ltbl(WIN), gtbl + (int64_t)l * PWL_TBL, TO_BASE ? of : uf, th, general);
+        // The backward never reads a layer's conditioned OUTPUT: data -> base takes the spline partials at the layer's
+        // input (cond_spline_bwd<INV = false>), base -> data at the output, which cond_spline_bwd forms itself in the
+        // bin it selects (consistent with its own knots; see pass_bwd).  So the last layer's table lookup, softmax and
+        // spline -- whose result nothing downstream reads -- are skipped here
+        if (step != L - 1) {
+          float th[PWL_P];
+          bool general;
+          pwl_eval<WIN>(tbl + l * pwl_ltbl(WIN), gtbl + (int64_t)l * PWL_TBL, TO_BASE ? of : uf, th, general);
 #pragma unroll
-        for (int m2 = 0; m2 < 2 * K; ++m2) th[m2] *= LN2;                        // table rows: log2 units ...
+          for (int m2 = 0; m2 < 2 * K; ++m2) th[m2] *= LN2;                        // table rows: log2 units ...
 #pragma unroll
-        for (int m2 = 2 * K; m2 < PWL_P; ++m2) th[m2] = fmaf(th[m2], LN2, -sc.sp_offset);   // ... slopes with the offset added
-        cond_spline<K, INV, true, float>(th, uo, sc, oo, ld);
-        in_f[step] = uf; in_o[step] = uo; out_f[step] = of; out_o[step] = oo;
+          for (int m2 = 2 * K; m2 < PWL_P; ++m2) th[m2] = fmaf(th[m2], LN2, -sc.sp_offset);   // ... slopes with the offset added
+          cond_spline<K, INV, true, float>(th, uo, sc, oo, ld);
+        }
+        in_f[step] = uf; in_o[step] = uo; out_f[step] = of;
         u[odd ? 1 : 0] = of; u[odd ? 0 : 1] = oo;
       }
     }
@@ -797,7 +807,7 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
         float tb[PWL_P];
         int kk;
         float sb0, sb1;
-        const float ub_o = cond_spline_bwd<K, INV, true, true>(th, in_o[step], out_o[step], ob_o, ld_bar, sc, tb, &kk, &sb0, &sb1);
+        const float ub_o = cond_spline_bwd<K, INV, true, true>(th, in_o[step], 0.0f, ob_o, ld_bar, sc, tb, &kk, &sb0, &sb1, true);
         const float* rowk = (p < WIN ? tl + PWL_OFF_PIECE + p * PWL_ROW : gl + PWL_OFF_PIECE + p * PWL_ROW) + 2 * K + kk;
         float ucond_bar = fmaf(rowk[0] * LN2, sb0, rowk[1] * LN2 * sb1);
 #pragma unroll

@@ -1,8 +1,8 @@
 """cnf_pass_vjp (MLP backward) over the event dimension: time per pass and per conditioner evaluation
 (a pass at dim D runs L * (D - 1) conditioners), 655 360 passes = the finite-difference score passes of
 config 4's per-GPU share."""
-import sys, time
-sys.path.insert(0, ".")
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cnf_ot_amd import FlowConfig, FlowEngine, Params
 dev = torch.device("cuda", 0)

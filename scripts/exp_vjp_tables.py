@@ -1,7 +1,7 @@
 """cnf_pass_vjp at dim 2: the table form (per-piece sufficient statistics) vs the MLP backward, one pass over
 32 slices x 131 072 points (config 5's per-GPU share) and 32 x 4 096 (config 3's time batch)."""
-import sys, time
-sys.path.insert(0, ".")
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cnf_ot_amd import FlowConfig, FlowEngine, Params
 dev = torch.device("cuda", 0)
