@@ -486,3 +486,46 @@ def test_table_backward_properties_at_config5_size(dev, to_base):
   _, gb = run(S // 2, S)
   assert ((ga + gb) - g).abs().max().item() <= 2e-6 * g.abs().max().item()
   assert torch.isfinite(g).all() and g.abs().max().item() > 0
+
+
+def test_inverse_direction_backward_next_to_a_knot(dev):
+  """Regression (found by scripts/soak_vjp_tables.py, seed 1 case 16): base -> data samples whose conditioned spline
+  lands within a rounding of a knot.  The backward used the forward pass's output with its own, differently rounded
+  knots; the position clipped and the implicit-function quotient gave input adjoints of 3e9 where the float64
+  oracle's central differences give 0.02.  Both backward kernels (MLP and tables) against those differences."""
+  import oracle
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  cfg = FlowConfig(dim=2); ocfg = oracle.OracleConfig(D=2)
+  rng = np.random.default_rng(1)
+  for case in range(17):                       # the soak's draws, up to its case 16
+    scale = float(rng.choice([0.05, 0.1, 0.2, 0.3, 0.5, 0.8, 1.5]))
+    spread = float(rng.choice([1.0, 2.0, 4.0, 6.0]))
+    amag = float(10.0 ** rng.uniform(-6, 4))
+    w = rng.normal(0, scale, cfg.param_count()).astype(np.float32)
+    S, Bs = 4, 9000
+    B = S * Bs
+    pts = rng.normal(0, spread, (B, 2)).astype(np.float32)
+    ybar = (rng.normal(0, 1, (B, 2)) * amag).astype(np.float32)
+    ldbar = (rng.normal(0, 1, B) * amag).astype(np.float32)
+    ts = rng.uniform(0, 1, S).astype(np.float32)
+  assert (scale, spread) == (0.5, 6.0)
+  eng = FlowEngine(cfg, dev).load(Params(cfg, torch.from_numpy(w).to(dev)))
+  t_dev = torch.from_numpy(ts).to(dev)
+  c_host = np.repeat(ts.astype(np.float64), Bs)
+  h = 1e-6
+  for mode in (0, 2):
+    eng.set_pwl(mode)
+    g = torch.zeros(cfg.param_count(), device=dev)
+    xb = eng.pass_vjp(torch.from_numpy(pts).to(dev), t_dev if mode == 2 else t_dev.repeat_interleave(Bs)[:, None],
+                      torch.from_numpy(ybar).to(dev), torch.from_numpy(ldbar).to(dev), False, grad=g)
+    xb = xb.cpu().double().numpy()
+    assert np.isfinite(xb).all() and np.abs(xb).max() < 1e3, np.abs(xb).max()       # was 3.2e9
+    for i in (1096, 7700, 8733):
+      ref = np.zeros(2)
+      for e in range(2):
+        xp = pts[i:i + 1].astype(np.float64).copy(); xm = xp.copy(); xp[0, e] += h; xm[0, e] -= h
+        yp, lp = oracle.forward_logdet(ocfg, w.astype(np.float64), xp, c_host[i:i + 1])
+        ym, lm = oracle.forward_logdet(ocfg, w.astype(np.float64), xm, c_host[i:i + 1])
+        ref[e] = ((yp - ym)[0] @ ybar[i].astype(np.float64) + (lp - lm)[0] * float(ldbar[i])) / (2 * h)
+      # an ill-conditioned flow (parameter scale 0.5, points out to |x| = 16) in float32: the right magnitude and sign
+      assert np.abs(xb[i] - ref).max() <= 0.6 * np.abs(ref).max() + 1e-4, (mode, i, xb[i], ref)
