@@ -23,6 +23,7 @@ namespace cnf {
 struct BinPartials {
   float f_x, f_x0, f_bw, f_bh, f_d0, f_d1;
   float l_x, l_x0, l_bw, l_bh, l_d0, l_d1;
+  float f_y0;      // 1 inside the range; 0 on the linear tails, which hang on the fixed corners (lo, lo) / (hi, hi)
 };
 
 // FAST: v_rcp_f32 (1 ulp) for the six reciprocals instead of IEEE division (ten instructions each)
@@ -59,11 +60,12 @@ __device__ __forceinline__ BinPartials rqs_partials(float x, float x0, float bw,
   p.l_bh = l_s * ibw;
   p.l_d0 = omz * omz * iA - 2.0f * q * iden;
   p.l_d1 = z * z * iA - 2.0f * q * iden;
+  p.f_y0 = 1.0f;
   if (x <= lo) {        // linear tail through (lo, lo) with slope d0 of bin 0
-    p = BinPartials{d0, 0.f, 0.f, 0.f, x - lo, 0.f, 0.f, 0.f, 0.f, 0.f, M::rcp(d0), 0.f};
+    p = BinPartials{d0, 0.f, 0.f, 0.f, x - lo, 0.f, 0.f, 0.f, 0.f, 0.f, M::rcp(d0), 0.f, 0.f};
   }
   if (x >= hi) {        // linear tail through (hi, hi) with slope d1 of the last bin
-    p = BinPartials{d1, 0.f, 0.f, 0.f, 0.f, x - hi, 0.f, 0.f, 0.f, 0.f, 0.f, M::rcp(d1)};
+    p = BinPartials{d1, 0.f, 0.f, 0.f, 0.f, x - hi, 0.f, 0.f, 0.f, 0.f, 0.f, M::rcp(d1), 0.f};
   }
   return p;
 }
@@ -80,7 +82,7 @@ __device__ __forceinline__ BinAdjoint bin_adjoint(const BinPartials& p, float o_
   if (!INV) {
     a.v = o_bar * p.f_x + l_bar * p.l_x;
     a.x0 = o_bar * p.f_x0 + l_bar * p.l_x0;
-    a.y0 = o_bar;
+    a.y0 = o_bar * p.f_y0;      // (the upper tail does not move with the last knot's y: found by scripts/soak_xbar_oracle.py)
     a.bw = o_bar * p.f_bw + l_bar * p.l_bw;
     a.bh = o_bar * p.f_bh + l_bar * p.l_bh;
     a.d0 = o_bar * p.f_d0 + l_bar * p.l_d0;
@@ -88,7 +90,7 @@ __device__ __forceinline__ BinAdjoint bin_adjoint(const BinPartials& p, float o_
   } else {
     a.v = (o_bar - l_bar * p.l_x) * Math<FAST>::rcp(p.f_x);
     a.x0 = -(p.f_x0 * a.v + l_bar * p.l_x0);
-    a.y0 = -a.v;
+    a.y0 = -a.v * p.f_y0;
     a.bw = -(p.f_bw * a.v + l_bar * p.l_bw);
     a.bh = -(p.f_bh * a.v + l_bar * p.l_bh);
     a.d0 = -(p.f_d0 * a.v + l_bar * p.l_d0);
