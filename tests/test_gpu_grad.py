@@ -48,7 +48,7 @@ def _fd_grad(fn, params64, idx):
   return out[0], ok
 
 
-def _run(dev, D, kind_spec, B, n_slices, shared, scale_params, seed, rtol, name):
+def _run(dev, D, kind_spec, B, n_slices, shared, scale_params, seed, rtol, name, spread=1.5):
   from oracle_backend import OracleBackend
   from cnf_ot_amd import FlowConfig, FlowEngine, Params
   cfg = FlowConfig(dim=D)
@@ -56,7 +56,7 @@ def _run(dev, D, kind_spec, B, n_slices, shared, scale_params, seed, rtol, name)
   eng = FlowEngine(cfg, dev).load(params)
   pts = eng.normal(seed + 1, B if shared else B * n_slices)
   if kind_spec.kind == 5:            # NEG_LOGPROB: data points, not base noise
-    pts = pts * 1.5 + 0.3
+    pts = pts * spread + 0.3
   t = np.linspace(0.2, 0.8, n_slices).astype(np.float32)
   grad = torch.zeros(cfg.param_count(), device=dev)
   sums = eng.loss_terms_grad(kind_spec, pts, t, B, shared, 1.0, grad)
@@ -100,6 +100,15 @@ def test_grad_direct_terms(dev):
   for sub in (0, 1, 2):
     _run(dev, 2, _spec(_capi.TERM_POTENTIAL, subtype=sub, a=1.0), 200, 2, True, 0.2, 4 + sub, 1e-3, f"potential{sub}")
   _run(dev, 2, _spec(_capi.TERM_REVERSE_KL, T=1.0, beta=4.0), 300, 1, True, 0.2, 8, 1e-3, "reverse_kl")
+
+
+def test_grad_with_points_on_the_linear_tails(dev):
+  """The density-fit term's parameter gradient with a quarter of the points beyond the splines' range (|x| > 10):
+  the tails' slopes are conditioner outputs, so the weight gradient sees them (and saw the upper tail wrongly before
+  `BinPartials::f_y0`)."""
+  from cnf_ot_amd import _capi
+  _run(dev, 2, _spec(_capi.TERM_NEG_LOGPROB), 300, 1, True, 0.2, 31, 1e-3, "neg_logprob_tails", spread=7.0)
+  _run(dev, 3, _spec(_capi.TERM_NEG_LOGPROB), 200, 1, True, 0.15, 32, 1e-3, "neg_logprob_tails_d3", spread=7.0)
 
 
 def test_grad_finite_difference_terms(dev):
