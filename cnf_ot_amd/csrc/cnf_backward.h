@@ -27,15 +27,16 @@ struct BinPartials {
 };
 
 // FAST: v_rcp_f32 (1 ulp) for the six reciprocals instead of IEEE division (ten instructions each)
+// rqs_partials_at: the position in the bin given as the pair (z, omz = 1 - z) -- a caller that knows the small one of
+// the two to full relative precision (cond_spline_bwd's inverse) passes it as such; x only decides the tails.
 template <bool FAST = false>
-__device__ __forceinline__ BinPartials rqs_partials(float x, float x0, float bw, float bh, float d0,
-                                                    float d1, float lo, float hi) {
+__device__ __forceinline__ BinPartials rqs_partials_at(float z, float omz, float x, float bw, float bh, float d0,
+                                                       float d1, float lo, float hi) {
   using M = Math<FAST>;
   BinPartials p;
   const float ibw = M::rcp(bw);
-  const float z = clip01((x - x0) * ibw);
   const float s = bh * ibw;
-  const float q = z - z * z, qp = 1.0f - 2.0f * z, omz = 1.0f - z;
+  const float q = z * omz, qp = omz - z;
   const float st = d0 + d1 - 2.0f * s;
   const float Nn = fmaf(s * z, z, d0 * q);
   const float den = fmaf(st, q, s);
@@ -44,8 +45,10 @@ __device__ __forceinline__ BinPartials rqs_partials(float x, float x0, float bw,
   const float iA = M::rcp(A);
   const float iden2 = iden * iden;
   p.f_x = s * s * A * iden2;
-  const float f_s = bh * (z * z * den - Nn * (1.0f - 2.0f * q)) * iden2;
-  p.f_d0 = bh * q * (den - Nn) * iden2;
+  // (forms without cancellation as q -> 0:  z^2 den - N (1 - 2q) = q (z^2 st - d0 + 2N),  den - N = omz (s omz + d1 z),
+  //  2/s - 2 (1 - 2q)/den = 2q (d0 + d1)/(s den) -- the differences lost two digits within 1e-4 of a knot)
+  const float f_s = bh * q * (fmaf(z * z, st, -d0) + 2.0f * Nn) * iden2;
+  p.f_d0 = bh * q * omz * fmaf(s, omz, d1 * z) * iden2;
   p.f_d1 = -bh * Nn * q * iden2;
   p.f_x0 = -p.f_x;
   p.f_bw = -p.f_x * z - f_s * s * ibw;
@@ -53,7 +56,7 @@ __device__ __forceinline__ BinPartials rqs_partials(float x, float x0, float bw,
   const float Az = 2.0f * (d1 * z + s * qp - d0 * omz);
   const float denz = st * qp;
   const float l_z = Az * iA - 2.0f * denz * iden;
-  const float l_s = 2.0f * M::rcp(s) + 2.0f * q * iA - 2.0f * (1.0f - 2.0f * q) * iden;
+  const float l_s = 2.0f * q * fmaf((d0 + d1) * iden, M::rcp(s), iA);
   p.l_x = l_z * ibw;
   p.l_x0 = -p.l_x;
   p.l_bw = -(l_z * z + l_s * s) * ibw;
@@ -97,6 +100,13 @@ __device__ __forceinline__ BinAdjoint bin_adjoint(const BinPartials& p, float o_
     a.d1 = -(p.f_d1 * a.v + l_bar * p.l_d1);
   }
   return a;
+}
+
+template <bool FAST = false>
+__device__ __forceinline__ BinPartials rqs_partials(float x, float x0, float bw, float bh, float d0,
+                                                    float d1, float lo, float hi) {
+  const float z = clip01((x - x0) * Math<FAST>::rcp(bw));
+  return rqs_partials_at<FAST>(z, 1.0f - z, x, bw, bh, d0, d1, lo, hi);
 }
 
 // ---------------------------------------------------------------------------
@@ -175,17 +185,27 @@ __device__ __forceinline__ float cond_spline_bwd(const float (&th)[3 * K + 1], f
     kk += ge ? 1 : 0;
   }
   const float d0 = knot_slope<FAST, float>(t0, sc), d1 = knot_slope<FAST, float>(t1, sc);
+  BinPartials p;
   if (INV && form_out) {      // rqs_bin_eval's inverse branch and cond_spline's linear tails
+    // The quadratic is solved from the nearer end of the bin (the spline is symmetric under z <-> 1 - z, d0 <-> d1,
+    // dy <-> bh - dy), so the SMALL one of z and 1 - z comes out to full relative precision: where the inverse
+    // saturates against a knot, 1 - z recovered from the float32 output is good to a few per cent only, and the
+    // log-det partials divide by it (scripts/debug_xbar_tail.py)
     const float sl = bh * M::rcp(bw), st = d0 + d1 - 2.0f * sl;
-    const float dy = fminf(fmaxf(v - y0, 0.0f), bh);
-    const float c = -sl * dy, b = fmaf(-st, dy, d0 * bh), a2 = fmaf(sl, bh, -b);
+    const float dy = fminf(fmaxf(v - y0, 0.0f), bh), dyt = bh - dy;
+    const bool low = dy <= dyt;
+    const float t = low ? dy : dyt, da = low ? d0 : d1;
+    const float c = -sl * t, b = fmaf(-st, t, da * bh), a2 = fmaf(sl, bh, -b);
     const float disc = fmaf(b, b, a2 * c * -4.0f);
-    const float z = clip01(M::div(c * -2.0f, b + M::sqrt(disc)));
-    out = fmaf(bw, z, x0);
+    const float r = clip01(M::div(c * -2.0f, b + M::sqrt(disc)));
+    const float z = low ? r : 1.0f - r, omz = low ? 1.0f - r : r;
+    out = low ? fmaf(bw, r, x0) : fmaf(-bw, r, x0 + bw);
     if (v <= sc.lo) out = fmaf(v - sc.lo, M::rcp(d0), sc.lo);
     if (v >= sc.hi) out = fmaf(v - sc.hi, M::rcp(d1), sc.hi);
+    p = rqs_partials_at<FAST>(z, omz, out, bw, bh, d0, d1, sc.lo, sc.hi);
+  } else {
+    p = rqs_partials<FAST>(INV ? out : v, x0, bw, bh, d0, d1, sc.lo, sc.hi);
   }
-  const BinPartials p = rqs_partials<FAST>(INV ? out : v, x0, bw, bh, d0, d1, sc.lo, sc.hi);
   const BinAdjoint a = bin_adjoint<INV, FAST>(p, o_bar, l_bar);
   // widths: w_j = span p_j + min_bin, x0 = lo + sum_{j<k} w_j, bw = w_k
   //   theta_bar_j = span p_j (wbar_j - sum_i wbar_i p_i)
