@@ -26,6 +26,7 @@ extras : (rank 0, N=1) per-kernel HIP-event times of the same calls (roofline),
          headline metric; own metric string.
 
   python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus N --steps K --warmup W          (starts its own N ranks as child processes)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -78,6 +79,8 @@ def parse_args():
   ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' + "
                   "--share-device rehearses the multi-rank path on a one-GPU box")
   ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+  ap.add_argument("--force-dist", action="store_true", help="initialise the process group even for ONE rank (checks "
+                  "the RCCL init / all-reduce / barrier path on a one-GPU box)")
   ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0: the fastest of "
                   "{affinity, cgroup quota, 64, 32, 16}, found by a short calibration)")
   return ap.parse_args()
@@ -283,25 +286,70 @@ def configs_section(dev):
   return out
 
 
+def _free_port():
+  import socket
+  with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+    s.bind(("127.0.0.1", 0))
+    return s.getsockname()[1]
+
+
+def self_launch(args):
+  """`python bench.py --gpus N` (N > 1) without a launcher in front: start the N ranks as CHILD processes through
+  torch.distributed.run -- the command the driver itself uses -- and hand back their return code.  This process has
+  made no GPU call yet (importing torch and counting devices do not initialise the GPU) and makes none: it only
+  waits, so nothing that touched the GPU is ever re-exec'ed.  Rank 0 of the children prints the JSON line on the
+  inherited stdout."""
+  import subprocess
+  n_dev = torch.cuda.device_count()
+  if not args.share_device and n_dev < args.gpus:
+    print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible (a one-GPU rehearsal needs "
+          f"--backend gloo --share-device)", file=sys.stderr, flush=True)
+    return 2
+  env = dict(os.environ)
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver
+  env.setdefault("OMP_NUM_THREADS", "4")
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.run(cmd, env=env).returncode
+
+
 def main():
   args = parse_args()
+  launched = "WORLD_SIZE" in os.environ
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if not launched and args.gpus > 1:
+    sys.exit(self_launch(args))
   if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     args.gpus = world
   assert torch.cuda.is_available(), "bench.py needs an MI355X (ROCm) device"
   dev = torch.device("cuda", 0 if args.share_device else local_rank)
   torch.cuda.set_device(dev)
   dist = None
-  if world > 1:
+  comm = {"world": world, "backend": None, "launcher": "torch.distributed.run" if launched else "none"}
+  if world > 1 or args.force_dist:
     import torch.distributed as dist
+    if not launched:                                     # --force-dist, one rank: a rendezvous of its own
+      os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+      os.environ.setdefault("MASTER_PORT", str(_free_port()))
+      os.environ.setdefault("RANK", "0")
+      os.environ.setdefault("WORLD_SIZE", "1")
     if args.backend == "nccl":
       dist.init_process_group("nccl", device_id=dev)
+      try:
+        comm["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+      except Exception as exc:      # reported, never fatal
+        comm["rccl_version"] = repr(exc)[:80]
     else:
       dist.init_process_group(args.backend)
+    comm["backend"] = dist.get_backend()
+    # one all-reduce through the backend before anything is timed: every rank contributes 1
+    chk = torch.ones(1, device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(chk)
+    comm["ranks_seen"] = int(chk.item())
+    assert comm["ranks_seen"] == world, "the all-reduce did not see every rank"
+  args._comm = comm
 
   def barrier():
     torch.cuda.synchronize()
@@ -390,6 +438,7 @@ def main():
       "batch": BATCH, "dim": DIM, "slices_per_step": args.slices, "samples_per_step": args.slices * BATCH,
       "slices_per_step_this_rank": S, "timed_region_s": elapsed,
       "parallelism": f"slice-shard x{world} (contiguous blocks of the step's slices; no collective)",
+      "comm": args._comm,
     },
     "cold_first_call_ms": cold_ms,
     "roofline": {
@@ -476,7 +525,8 @@ def workload_main(args, dev, dist, world, rank, barrier, max_over_ranks):
     "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
     "config": {"workload": desc, "global_batch": B, "flow_passes_per_step": passes,
                "parallelism": f"sample-shard x{world}; one sum all-reduce of partial sums + gradient "
-                              f"({params.flat.numel()} floats) per step"},
+                              f"({params.flat.numel()} floats) per step",
+               "comm": args._comm},
     "loss": float(loss),
   }
   if rank == 0:

@@ -114,3 +114,34 @@ def test_no_cpu_fallback_in_product_path():
         with open(os.path.join(dirpath, fn)) as f:
           src = f.read()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+
+
+def test_bench_starts_its_own_ranks_as_child_processes(monkeypatch):
+  """`python bench.py --gpus N` without a launcher: the N ranks are CHILD processes started through
+  torch.distributed.run before any GPU call of the parent (never an exec of a process that touched the GPU)."""
+  import subprocess, sys, types
+  sys.path.insert(0, ROOT)
+  import bench
+  seen = {}
+
+  def fake_run(cmd, env=None, **kw):
+    seen["cmd"], seen["env"] = cmd, env
+    return types.SimpleNamespace(returncode=7)
+
+  monkeypatch.setattr(subprocess, "run", fake_run)
+  monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "3"])
+  monkeypatch.delenv("WORLD_SIZE", raising=False)
+  with pytest.raises(SystemExit) as exc:
+    bench.main()
+  assert exc.value.code == 7                                   # the children's return code is handed back
+  cmd = seen["cmd"]
+  assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+  assert "--nproc-per-node=2" in cmd and "127.0.0.1" in cmd
+  assert cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:] == sys.argv[1:]
+  assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+  # without --share-device a box with fewer GPUs than ranks is refused before anything is started
+  seen.clear()
+  monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "64"])
+  with pytest.raises(SystemExit) as exc:
+    bench.main()
+  assert exc.value.code == 2 and not seen
