@@ -367,14 +367,58 @@ __device__ __forceinline__ WgradPre wgrad_prefetch(const float* __restrict__ gw,
 }
 
 // ---------------------------------------------------------------------------
-// The backward pass's conditioner work on the matrix cores (hidden 16, P = 16, one sample per lane).  A lone or
-// second wave per SIMD -- all the backward kernels' LDS working set allows -- issues one VALU instruction per ~8
-// cycles, and the 544-FMA conditioner recompute plus the two 256-FMA data-backprop products are most of a
-// backward pass; as 16x16x4 fp32 MFMAs they are 64 instructions.  Everything stays in the MFMA operand layout of
-// conditioner_mfma (lane (g, s), register r: unit 4g + r of sample 16q + s of group q) from the recompute through
-// the ReLU masks to the weight-gradient staging; only theta (out), theta_bar (in) and the first-layer adjoint
-// cross to / from the lane-per-sample layout, by the same 4x4 permlane transpose.
+// The backward pass's conditioner work on the matrix cores (hidden 16, P = 16, one sample per lane, 64 samples =
+// 4 groups of 16 per wave).  EVERY matrix product of a conditioner -- the three layers of the (re)computation, the
+// three data-backprop products and the three weight-gradient GEMMs -- is a run of v_mfma_f32_16x16x4_f32, and no
+// loop over the d conditioning inputs is left on the vector ALU (round 2 evaluated the first layer, its weight
+// gradient's operand and the input adjoints per lane in runtime loops over d: scalar weight loads and LDS round trips
+// waited for one after the other, ~1 500 vector instructions per conditioner at dim 10).
+//
+// Operand layouts (lane l: g = l >> 4, i = s = l & 15; checked on hardware by scripts/probes/mfma_probe.hip):
+//   A lane (g, i) holds A[i][k = g], B lane (g, s) holds B[k = g][n = s], result lane (g, s) register r holds
+//   D[row 4g + r][col s].  Hidden layers permute k to 4g + t (step t) so that a layer's result registers ARE the next
+//   layer's B operands ("MFMA layout": lane (g, s), register r of group q: unit 4g + r of sample 16q + s).
+// First layer: the inputs [c, v_1 .. v_d, 1] (the constant row carries the bias) are ROWS of the tile's LDS buffers
+// (a row = one input dimension, 64 consecutive samples per wave), so the B operand of step t, k = 4t + g, is one
+// ds_read_b32 per group at row k, and steps beyond ceil((d + 2) / 4) are skipped; the A operand of that step is the
+// flat weight block itself, W0pad[k][i] = wflat[16 k + i] (rows 0 .. d: W0, row d + 1: b0 -- contiguous in the
+// flat layout).  The same rows, read 16 bytes per lane along the samples, are the A operand of the first layer's
+// weight-gradient GEMM (K = samples): rows are GTS + 4 floats apart, so the 16 lanes of a group hit 64 different banks.
 // ---------------------------------------------------------------------------
+struct CondGeom {
+  int in_off;       // LDS offset (floats) of row 0 of the buffer that holds the conditioning inputs, at the wave's first sample
+  int c_off;        // ... of the wave's 64 conditions
+  int ones_off;     // ... of 64 x 1.0f (shared by the workgroup)
+  int first_idx, idx_step, stride, d;
+};
+
+// LDS offset of input row k of a conditioner: k = 0 the condition, 1 .. d the conditioning inputs, d + 1 (and beyond:
+// the callers discard or zero what comes of those rows) ones
+__device__ __forceinline__ int cond_row_off(const CondGeom& G, int k) {
+  int kk = k < 1 ? 1 : k;
+  kk = kk > G.d ? G.d : kk;
+  int off = G.in_off + (G.first_idx + (kk - 1) * G.idx_step) * G.stride;
+  off = k == 0 ? G.c_off : off;
+  off = k > G.d ? G.ones_off : off;
+  return off;
+}
+
+// The weights of one conditioner's forward evaluation in MFMA operand form: fetched (global memory, L2) one
+// conditioner AHEAD of their use -- a dependent L2 round trip costs a lone wave 1-2 us, as long as the conditioner's
+// arithmetic.  a0[t]: W0pad[4t + g][i] (0 beyond row d + 1); A1 / A2, bias1 / bias2: the 16 x 16 layers (prepare_kernel's `wq`).
+// (the output layer's A2 / bias2 are fetched at the start of the evaluation itself: the first two layers cover them)
+struct CondW { float a0[4]; f4 A1, bias1; const f4* p2; };
+
+__device__ __forceinline__ CondW cond_weights(const f4* __restrict__ wq, const float* __restrict__ wflat, int d) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
+  const f4* p = wq + (2 + d) * 64;
+  CondW w;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) w.a0[t] = 4 * t + g <= d + 1 ? wflat[(4 * t + g) * 16 + s] : 0.0f;
+  w.A1 = p[lane]; w.bias1 = p[64 + lane]; w.p2 = p + 128 + lane;
+  return w;
+}
+
 // MFMA-layout values -> a staging region ([unit][sample], row stride STG): unit 4g + t of sample 16q + i
 __device__ __forceinline__ void stage_m(float* region, const float (&m)[4][4]) {
   const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
@@ -384,102 +428,51 @@ __device__ __forceinline__ void stage_m(float* region, const float (&m)[4][4]) {
     for (int t = 0; t < 4; ++t) region[(4 * g + t) * STG + 16 * q + i] = m[q][t];
   }
 }
-// bit 4q + t: m[q][t] > 0 (the ReLU mask of a hidden layer, 16 bits instead of 16 registers)
-__device__ __forceinline__ uint32_t mask_m(const float (&m)[4][4]) {
-  uint32_t bits = 0;
+
+constexpr int STAGE_FLOATS = 2 * 16 * STG;       // per wave: region 0 [h2, then h1], region 1 [theta_bar, then g2, then g1]
+
+// Conditioner forward (M = 2) on the matrix cores: theta in the lane layout; both hidden activations are handed back
+// in MFMA layout (the backward's ReLU masks are their signs, and they are the operands of its weight-gradient GEMMs).
+__device__ __forceinline__ void cond_fwd_mfma(const float* lds, const CondGeom& G, const CondW& w, float (&h1m)[4][4],
+                                              float (&h2m)[4][4], float (&th)[16]) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
+  const int nst = (G.d + 5) >> 2;                  // k-steps of the first layer: ceil((d + 2) / 4)
+  const f4 A2 = w.p2[0], bias2 = w.p2[64];
+  __builtin_amdgcn_sched_barrier(0);
+  f4 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < nst) {                                 // (wave-uniform)
+      const float* row = lds + cond_row_off(G, 4 * t + g) + s;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.a0[t], row[16 * q], acc[q], 0, 0, 0);
+    }
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bits |= (m[q][t] > 0.0f ? 1u : 0u) << (4 * q + t);
+    for (int t = 0; t < 4; ++t) h1m[q][t] = fmaxf(acc[q][t], 0.0f);
   }
-  return bits;
-}
-
-constexpr int STAGE_FLOATS = 3 * 16 * STG;       // per wave: [h1 operand, kept][a operand][b operand]
-
-// conditioner forward (M = 2) on MFMA for the backward pass: theta in lane layout, the second hidden layer's
-// activations in MFMA layout, the first one's STAGED in the wave's h1 region (it is only needed again as a
-// weight-gradient operand) with its ReLU mask as 16 bits; `wq` as in conditioner_mfma
-// theta only (the forward-with-stash pass of the backward kernels): first layer as above, the two 16 x 16 layers on
-// the matrix cores
-__device__ __forceinline__ void conditioner_mfma_lane1(const f4* __restrict__ wq, uniform_ptr w, int d, float c,
-                                                       const float* col, int first_idx, int idx_step, int stride,
-                                                       float (&th)[16]) {
-  const int lane = threadIdx.x & 63;
-  const f4* p = wq + (2 + d) * 64;
-  const f4 A1 = p[lane], bias1 = p[64 + lane], A2 = p[128 + lane], bias2 = p[192 + lane];
-  float h1[16], hm[4][4];
-  first_layer_lane<float>(w, d, c, col, first_idx, idx_step, stride, h1);
-  to_mfma_layout(h1, hm);
-  f4 acc[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = bias1;
+  for (int q = 0; q < 4; ++q) acc[q] = w.bias1;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[t], hm[q][t], acc[q], 0, 0, 0);
+    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.A1[t], h1m[q][t], acc[q], 0, 0, 0);
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) hm[q][t] = fmaxf(acc[q][t], 0.0f);
+    for (int t = 0; t < 4; ++t) h2m[q][t] = fmaxf(acc[q][t], 0.0f);
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc[q] = bias2;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[t], hm[q][t], acc[q], 0, 0, 0);
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) hm[q][r] = acc[q][r];
-  }
-  from_mfma_layout(hm, th);
-}
-
-__device__ __forceinline__ void conditioner_mfma_keep(const f4* __restrict__ wq, uniform_ptr w, int d, float c,
-                                                      const float* col,
-                                                      int first_idx, int idx_step, int stride, float* stage,
-                                                      uint32_t& mask1, float (&h2m)[4][4], float (&th)[16]) {
-  const int lane = threadIdx.x & 63;
-  float h1m[4][4];
-  {
-    float h1[16];
-    first_layer_lane<float>(w, d, c, col, first_idx, idx_step, stride, h1);
-    to_mfma_layout(h1, h1m);
-  }
-  mask1 = mask_m(h1m);
-  __builtin_amdgcn_wave_barrier();
-  stage_m(stage, h1m);
-  __builtin_amdgcn_wave_barrier();
-  const f4* p = wq + (2 + d) * 64;
-  f4 acc[4];
-  {
-    const f4 A = p[lane], bias = p[64 + lane];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = bias;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t], h1m[q][t], acc[q], 0, 0, 0);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) h2m[q][t] = fmaxf(acc[q][t], 0.0f);
-    }
-  }
-  {
-    const f4 A = p[128 + lane], bias = p[192 + lane];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = bias;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t], h2m[q][t], acc[q], 0, 0, 0);
-    }
+    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[t], h2m[q][t], acc[q], 0, 0, 0);
   }
   float thm[4][4];
 #pragma unroll
@@ -488,6 +481,14 @@ __device__ __forceinline__ void conditioner_mfma_keep(const f4* __restrict__ wq,
     for (int r = 0; r < 4; ++r) thm[q][r] = acc[q][r];
   }
   from_mfma_layout(thm, th);
+}
+
+// The A operands of a conditioner's three data-backprop products, out_i = sum_j W[i][j] in_j with j = 4g + t: one
+// 16-byte load each from the flat weights.  The output layer's is issued before the spline backward (which covers the
+// round trip), the other two at the start of the conditioner backward (covered by its first stage).
+__device__ __forceinline__ f4 cond_weight_T(const float* __restrict__ wmat) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+  return *reinterpret_cast<const f4*>(wmat + i * 16 + 4 * g);
 }
 
 // dW += a b^T over the wave's 64 samples from STAGED operands ([unit][sample] regions)
@@ -518,29 +519,46 @@ __device__ __forceinline__ void wgrad_staged(const float* sa, const float* sb, f
   }
 }
 
-// Conditioner backward with the two data-backprop products on MFMA.  `wflat`: this conditioner's weights in the
-// flat layout (global memory): the A operand of out_i = sum_j W[i][j] in_j is W[i][4g .. 4g+3], one 16-byte load.
-// `stage`: [h1 region (filled by conditioner_mfma_keep)][a][b].
-template <bool WGRAD = true>
-__device__ __forceinline__ void conditioner_bwd_mfma(const float* __restrict__ wflat, uniform_ptr w, int d, float c,
-                                                     const float* col, int first_idx, int idx_step, int stride,
-                                                     uint32_t mask1, const float (&h2m)[4][4],
-                                                     const float (&tb)[16], float* adj_col, float* __restrict__ gw,
-                                                     float* stage, const WgradPre& pre) {
-  w = launder(w);
+// The first layer's weight gradient: dW0pad[k][j] += sum_samples in_k g1_j, the A operand read straight from the
+// input rows (row k = lane's i; the ones row yields the bias gradient as row d + 1), the B operand staged.
+__device__ __forceinline__ void wgrad_inputs(const float* lds, const CondGeom& G, const float* sb,
+                                             float* __restrict__ dW, WgradAcc pre) {
   const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+  const float* ra = lds + cond_row_off(G, i) + 16 * g;
+  f4 av[4], bv[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    av[n] = *reinterpret_cast<const f4*>(ra + 4 * n);
+    bv[n] = *reinterpret_cast<const f4*>(sb + i * STG + 16 * g + 4 * n);
+  }
+  f4 acc = pre.acc;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[n][e], bv[n][e], acc, 0, 0, 0);
+  }
+  const int n_rows = G.d + 2;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) if (4 * g + r < n_rows) dW[(4 * g + r) * 16 + i] = acc[r];
+}
+
+// Conditioner backward on the matrix cores.  h1m / h2m: the hidden activations of cond_fwd_mfma, tb: theta_bar in the
+// lane layout, adj_off: LDS offset (wave's first sample, row 0) of the buffer that receives the adjoints of the
+// conditioning inputs, gw: this conditioner's block of the wave's gradient slab.  Staging (two [unit][sample] regions
+// per wave): h2 | theta_bar -> dWo;  h1 | g2 -> dW1;  (input rows) | g1 -> dW0.
+template <bool WGRAD = true>
+__device__ __forceinline__ void cond_bwd_mfma(float* lds, const CondGeom& G, int adj_off, const float* __restrict__ wflat,
+                                              f4 Ao, const float (&h1m)[4][4], const float (&h2m)[4][4],
+                                              const float (&tb)[16], float* __restrict__ gw, float* stage, WgradAcc pre_o) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+  const int d = G.d;
   const int o_b0 = (1 + d) * 16, o_w1 = o_b0 + 16, o_b1 = o_w1 + 256, o_wo = o_b1 + 16, o_bo = o_wo + 256;
-  float* s1 = stage;
-  float* sa = stage + 16 * STG;
-  float* sb = stage + 32 * STG;
-  // both A operands now: two independent L2 round trips that would otherwise be waited for one after the other,
-  // right in front of their MFMAs
-  const f4 Ao = *reinterpret_cast<const f4*>(wflat + o_wo + i * 16 + 4 * g);
-  const f4 A1 = *reinterpret_cast<const f4*>(wflat + o_w1 + i * 16 + 4 * g);
-#ifdef CNF_BWD_HOIST_A
+  float* sa = stage;
+  float* sb = stage + 16 * STG;
+  const f4 A1 = cond_weight_T(wflat + o_w1), A0 = cond_weight_T(wflat);       // (A0: rows beyond d give results nobody reads)
+  [[maybe_unused]] WgradAcc pre_h, pre_f;
+  if constexpr (WGRAD) { pre_h = wgrad_fetch(gw + o_w1, 16, gw + o_b1); pre_f = wgrad_fetch(gw, d + 2, nullptr); }
   __builtin_amdgcn_sched_barrier(0);
-#endif
-  const uint32_t mask2 = mask_m(h2m);
   float tbm[4][4];
   to_mfma_layout(tb, tbm);
   if constexpr (WGRAD) {
@@ -548,7 +566,7 @@ __device__ __forceinline__ void conditioner_bwd_mfma(const float* __restrict__ w
     stage_m(sa, h2m);
     stage_m(sb, tbm);
     __builtin_amdgcn_wave_barrier();
-    wgrad_staged(sa, sb, gw + o_wo, gw + o_bo, pre.o);
+    wgrad_staged(sa, sb, gw + o_wo, gw + o_bo, pre_o);
   }
   float g2m[4][4];
   {
@@ -563,16 +581,17 @@ __device__ __forceinline__ void conditioner_bwd_mfma(const float* __restrict__ w
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) g2m[q][r] = (mask2 >> (4 * q + r)) & 1u ? acc[q][r] : 0.0f;
+      for (int r = 0; r < 4; ++r) g2m[q][r] = h2m[q][r] > 0.0f ? acc[q][r] : 0.0f;
     }
   }
   if constexpr (WGRAD) {
     __builtin_amdgcn_wave_barrier();
+    stage_m(sa, h1m);
     stage_m(sb, g2m);
     __builtin_amdgcn_wave_barrier();
-    wgrad_staged(s1, sb, gw + o_w1, gw + o_b1, pre.h);
+    wgrad_staged(sa, sb, gw + o_w1, gw + o_b1, pre_h);
   }
-  float g1[16];
+  float g1m[4][4];
   {
     f4 acc[4];
 #pragma unroll
@@ -582,36 +601,38 @@ __device__ __forceinline__ void conditioner_bwd_mfma(const float* __restrict__ w
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[t], g2m[q][t], acc[q], 0, 0, 0);
     }
-    float g1m[4][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) g1m[q][r] = (mask1 >> (4 * q + r)) & 1u ? acc[q][r] : 0.0f;
+      for (int r = 0; r < 4; ++r) g1m[q][r] = h1m[q][r] > 0.0f ? acc[q][r] : 0.0f;
     }
-    from_mfma_layout(g1m, g1);
   }
-  // first layer: inputs [c, v_0..v_{d-1}, 1] (the constant row yields the bias gradient), lane layout
   if constexpr (WGRAD) {
-    float in[16];
+    __builtin_amdgcn_wave_barrier();
+    stage_m(sb, g1m);
+    __builtin_amdgcn_wave_barrier();
+    wgrad_inputs(lds, G, sb, gw, pre_f);
+  }
+  // adjoints of the conditioning inputs: row k = 4g + r of W0 g1 belongs to input k (1 .. d); every (input, sample)
+  // has exactly one owner lane-register, so the accumulation is a plain read-modify-write
+  {
+    f4 acc[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) in[r] = 0.0f;
-    in[0] = c;
-    for (int q = 0; q < d && q < 14; ++q) {
-      const float v = col[(first_idx + q * idx_step) * stride];
+    for (int q = 0; q < 4; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 1; r < 15; ++r) in[r] = (r == q + 1) ? v : in[r];
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[t], g1m[q][t], acc[q], 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 1; r < 16; ++r) in[r] = (r == d + 1) ? 1.0f : in[r];
-    wgrad_mfma(sa, in, g1, gw, d + 2, nullptr, pre.f);
-  }
-  for (int q = 0; q < d; ++q) {          // adjoints of the conditioning inputs
-    float wr[16];
-    load_row<16>(w + (1 + q) * 16, wr);
-    float acc = 0.0f;
+    for (int r = 0; r < 4; ++r) {
+      const int k = 4 * g + r;
+      if (k >= 1 && k <= d) {
+        float* row = lds + adj_off + (G.first_idx + (k - 1) * G.idx_step) * G.stride + i;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc = fmaf(wr[j], g1[j], acc);
-    adj_col[(first_idx + q * idx_step) * stride] += acc;
+        for (int q = 0; q < 4; ++q) row[16 * q] += acc[q][r];
+      }
+    }
   }
 }
 

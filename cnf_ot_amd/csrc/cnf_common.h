@@ -3,6 +3,7 @@
 #pragma once
 #include <mutex>
 #include <map>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -141,6 +142,45 @@ static inline bool ensure_lds(K kernel, size_t bytes) {
   const bool ok = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
   done[key] = ok;
   return ok;
+}
+
+// Workgroups of `kernel` (threads, dynamic LDS bytes) that fit on one CU at a time (registers, LDS, waves), cached.
+template <class K>
+static inline int resident_blocks_per_cu(K kernel, int threads, size_t lds) {
+  static std::mutex mu;
+  static std::map<std::tuple<const void*, int, size_t, int>, int> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 1;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_tuple((const void*)kernel, threads, lds, dev);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kernel, threads, lds) != hipSuccess || n < 1) n = 1;
+  // The API has been seen one workgroup per CU high (MI355X_MICROARCH.md: kernels with 81-112 SGPRs; here: 6 reported
+  // for 27.8 KB of LDS per workgroup, 5 resident -- profiles/r03b_cfg4), and a grid one round larger than what is
+  // resident costs a whole extra round: bound it by the two limits that can be computed here.
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, (const void*)kernel) == hipSuccess) {
+    const size_t per_wg = ((lds + fa.sharedSizeBytes + 511) / 512) * 512;              // LDS allocation granularity
+    if (per_wg > 0) { const int by_lds = (int)((160 * 1024) / per_wg); if (by_lds >= 1 && by_lds < n) n = by_lds; }
+    const int regs = ((fa.numRegs > 0 ? fa.numRegs : 1) + 7) / 8 * 8;                  // unified VGPR file: 512 per SIMD lane
+    int waves_per_simd = 512 / regs; if (waves_per_simd > 8) waves_per_simd = 8;
+    const int by_regs = waves_per_simd * 4 / ((threads + 63) / 64);
+    if (by_regs >= 1 && by_regs < n) n = by_regs;
+  }
+  cache[key] = n;
+  return n;
+}
+
+// Grid of a kernel that walks `n_tiles` equal tiles with a grid-stride loop: never more workgroups than are resident at
+// once (`capacity`: a grid of 2 048 single-wave workgroups on 1 536 slots ran a second, quarter-filled round as long as
+// the first: profiles/r03a_cfg4), and every workgroup the same number of tiles, give or take one.
+static inline int64_t balanced_grid(int64_t n_tiles, int64_t capacity) {
+  if (capacity < 1) capacity = 1;
+  if (n_tiles <= capacity) return n_tiles < 1 ? 1 : n_tiles;
+  const int64_t per_block = (n_tiles + capacity - 1) / capacity;
+  return (n_tiles + per_block - 1) / per_block;
 }
 
 // Orders a compute call after the last cnf_model_set_params when that ran on a different stream.

@@ -28,24 +28,18 @@ constexpr int GP = 3 * GK + 1;     // 16 spline parameters
 // MFMA staging per wave, and at 1 wave per SIMD a wave issues at half rate with every latency exposed).
 #define GTS ((int)blockDim.x)
 constexpr int GTS_MAX = TILE;
-// experiment switches (scripts/exp_backward.sh; never set by the product build):
-//   CNF_BWD_VALU  the conditioner of the backward kernels on the vector ALU (the round-1 form)
-//   CNF_BWD_OCC1  let the backward kernels use up to 512 registers (one wave per SIMD)
-#ifdef CNF_BWD_VALU
-constexpr bool BWD_MFMA = false;
-#else
-constexpr bool BWD_MFMA = true;
-#endif
-#ifdef CNF_FWD_VALU
-constexpr bool FWD_MFMA = false;
-#else
-constexpr bool FWD_MFMA = true;
-#endif
-#ifdef CNF_BWD_OCC1
-#define CNF_BWD_MIN_BLOCKS 1
-#else
-#define CNF_BWD_MIN_BLOCKS 2
-#endif
+// LDS geometry of a tile.  Every [D][samples] buffer (noise, stashes, adjoints ...) has rows of GROW = GTS + 4 floats:
+// a wave's 64 samples of one input dimension are contiguous, and rows read 16 bytes per lane along the samples (the
+// A operand of the first layer's weight-gradient GEMM, cnf_backward.h) fall into different banks.  In front of them:
+// the `first` spline's table, 64 ones (the bias row of the first layer's MFMA operands) and the tile's condition column.
+#define GROW (GTS + 4)
+constexpr int HDRG = hdr_floats(GK);
+constexpr int ONES_OFF = HDRG, C_OFF = HDRG + 64;
+#define PRE_FLOATS (HDRG + 64 + GROW)
+
+__device__ __forceinline__ void tile_consts(float* lds) {
+  for (int i = threadIdx.x; i < 64; i += GTS) lds[ONES_OFF + i] = 1.0f;
+}
 
 struct GradArgs {
   ModelArgs m;
@@ -76,7 +70,7 @@ __device__ __forceinline__ void tile_load1(const float* __restrict__ g, float* U
   const int n_el = (int)(B - tile_start < GTS ? B - tile_start : GTS) * D;
   for (int e = threadIdx.x; e < GTS * D; e += GTS) {
     const int s = magic ? (int)__umulhi((uint32_t)e, magic) : e, d = e - s * D;
-    U[d * GTS + s] = e < n_el ? g[base + e] : 0.0f;
+    U[d * GROW + s] = e < n_el ? g[base + e] : 0.0f;
   }
 }
 
@@ -94,38 +88,50 @@ __device__ __forceinline__ int64_t cond_prefix(int d) {      // floats of condit
 // cache (the first version inlined 10 forward + 6 backward copies: 34 k
 // instructions, 4x the cache).
 template <bool FAST, int DFIX = 0>
-__device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, const float* tab, float* St, float c,
-                                                bool to_base) {
+__device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, float* lds, float* St, float c, bool to_base) {
   const int D = DFIX ? DFIX : a.D;
+  const float* tab = lds;
+  const int wbase = threadIdx.x & ~63;
+  lds[C_OFF + threadIdx.x] = c;
   uniform_ptr weights = as_uniform(a.prep + hdr_floats(GK));
   float acc = 0.0f;
   for (int s = 0; s < a.L; ++s) {
     const int l = to_base ? a.L - 1 - s : s;
     const bool odd = l & 1;
     const int first_idx = odd ? D - 1 : 0, idx_step = odd ? -1 : 1;
-    const float* cu = St + s * D * GTS + threadIdx.x;
-    float* co = St + (s + 1) * D * GTS + threadIdx.x;
-    float o, ld;
-    if (to_base) table_spline<GK, false, FAST, float>(tab, cu[first_idx * GTS], a.sc, o, ld);
-    else table_spline<GK, true, FAST, float>(tab, cu[first_idx * GTS], a.sc, o, ld);
-    co[first_idx * GTS] = o;
-    acc += ld;
+    const float* cu = St + s * D * GROW + threadIdx.x;
+    float* co = St + (s + 1) * D * GROW + threadIdx.x;
     uniform_ptr w = weights + l * a.per_layer;
+    [[maybe_unused]] const float* wflat = a.prep + hdr_floats(GK) + l * a.per_layer;
     [[maybe_unused]] const float* wq = a.wq + l * a.per_layer_q;
+    [[maybe_unused]] CondW cw;         // the NEXT conditioner's weights: one conditioner ahead (cnf_backward.h)
+    if constexpr (FAST) { if (D > 1) cw = cond_weights(reinterpret_cast<const f4*>(wq), wflat, 1); __builtin_amdgcn_sched_barrier(0); }
+    float o, ld;
+    if (to_base) table_spline<GK, false, FAST, float>(tab, cu[first_idx * GROW], a.sc, o, ld);
+    else table_spline<GK, true, FAST, float>(tab, cu[first_idx * GROW], a.sc, o, ld);
+    co[first_idx * GROW] = o;
+    acc += ld;
     for (int d = 1; d < D; ++d) {
       const int i = first_idx + d * idx_step;
       float th[GP];
-      if constexpr (FAST && BWD_MFMA && FWD_MFMA) {        // matrix cores (see cnf_backward.h); `wq` walks the MFMA-layout weights
-        conditioner_mfma_lane1(reinterpret_cast<const f4*>(wq), w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, th);
+      if constexpr (FAST) {        // matrix cores (cnf_backward.h); `wq` walks the MFMA-layout weights
+        const CondGeom G{(int)((to_base ? co : cu) - lds) - (int)threadIdx.x + wbase, C_OFF + wbase, ONES_OFF, first_idx,
+                         idx_step, GROW, d};
+        const CondW cur = cw;
         wq += cond_floats_mfma(d, 2);
+        wflat += cond_floats(d, 16, 2, GP);
+        if (d + 1 < D) cw = cond_weights(reinterpret_cast<const f4*>(wq), wflat, d + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        float h1m[4][4], h2m[4][4];
+        cond_fwd_mfma(lds, G, cur, h1m, h2m, th);
       } else {
-        conditioner<16, GP, float>(w, d, 2, c, to_base ? co : cu, first_idx, idx_step, GTS, th);
+        conditioner<16, GP, float>(w, d, 2, c, to_base ? co : cu, first_idx, idx_step, GROW, th);
+        w += cond_floats(d, 16, 2, GP);
       }
-      if (to_base) cond_spline<GK, false, FAST, float>(th, cu[i * GTS], a.sc, o, ld);
-      else cond_spline<GK, true, FAST, float>(th, cu[i * GTS], a.sc, o, ld);
-      co[i * GTS] = o;
+      if (to_base) cond_spline<GK, false, FAST, float>(th, cu[i * GROW], a.sc, o, ld);
+      else cond_spline<GK, true, FAST, float>(th, cu[i * GROW], a.sc, o, ld);
+      co[i * GROW] = o;
       acc += ld;
-      w += cond_floats(d, 16, 2, GP);
     }
   }
   return acc;
@@ -135,77 +141,95 @@ __device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, const float*
 // output on entry; the function ping-pongs between Aa and Ab and returns the
 // buffer that holds the adjoint of the pass input.
 template <bool FAST, bool WGRAD = true, int DFIX = 0>
-__device__ __forceinline__ float* pass_bwd(const ModelArgs& a, const float* tab, const float* St, float* Aa,
+__device__ __forceinline__ float* pass_bwd(const ModelArgs& a, float* lds, const float* St, float* Aa,
                                            float* Ab, float ld_bar, float c, bool to_base, float* gslab,
                                            float* stage, FirstAcc& fa) {
   const int D = DFIX ? DFIX : a.D;
+  const float* tab = lds;
+  const int wbase = threadIdx.x & ~63;
+  lds[C_OFF + threadIdx.x] = c;
   uniform_ptr weights = as_uniform(a.prep + hdr_floats(GK));
-  float* Ao = Aa;
-  float* Au = Ab;
+  float* Aout = Aa;
+  float* Ain = Ab;
   for (int s = a.L - 1; s >= 0; --s) {
     const int l = to_base ? a.L - 1 - s : s;
     const bool odd = l & 1;
     const int first_idx = odd ? D - 1 : 0, idx_step = odd ? -1 : 1;
-    const float* cu = St + s * D * GTS + threadIdx.x;
-    const float* co = St + (s + 1) * D * GTS + threadIdx.x;
-    float* ao = Ao + threadIdx.x;
-    float* au = Au + threadIdx.x;
-    for (int d = 0; d < D; ++d) au[d * GTS] = 0.0f;
+    const float* cu = St + s * D * GROW + threadIdx.x;
+    const float* co = St + (s + 1) * D * GROW + threadIdx.x;
+    float* ao = Aout + threadIdx.x;
+    float* au = Ain + threadIdx.x;
+    for (int d = 0; d < D; ++d) au[d * GROW] = 0.0f;
     int64_t off = cond_prefix(D);                     // end of this layer's conditioners
     [[maybe_unused]] int64_t offq = 0;                 // the same in the MFMA-layout weights
-    if constexpr (FAST && BWD_MFMA) { for (int dd = 1; dd < D; ++dd) offq += cond_floats_mfma(dd, 2); }
+    [[maybe_unused]] CondW cw;                         // the NEXT conditioner's recomputation weights, one conditioner ahead
+    if constexpr (FAST) {
+      for (int dd = 1; dd < D; ++dd) offq += cond_floats_mfma(dd, 2);
+      if (D > 1) {
+        cw = cond_weights(reinterpret_cast<const f4*>(a.wq + l * a.per_layer_q + offq - cond_floats_mfma(D - 1, 2)),
+                          a.prep + hdr_floats(GK) + l * a.per_layer + off - cond_floats(D - 1, 16, 2, GP), D - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     for (int d = D - 1; d >= 1; --d) {
       off -= cond_floats(d, 16, 2, GP);
       const int i = first_idx + d * idx_step;
-      uniform_ptr w = weights + l * a.per_layer + off;
       float* gw = WGRAD ? gslab + GP + l * a.per_layer + off : nullptr;
       WgradPre pre;
       float th[GP], tb[GP];
-      if constexpr (FAST && BWD_MFMA) {      // recompute and data backprop on the matrix cores (cnf_backward.h)
+      if constexpr (FAST) {      // recompute, data backprop and weight gradients on the matrix cores (cnf_backward.h)
         offq -= cond_floats_mfma(d, 2);
-        uint32_t mask1;
-        float h2m[4][4];
-        conditioner_mfma_keep(reinterpret_cast<const f4*>(a.wq + l * a.per_layer_q + offq), w, d, c, to_base ? co : cu,
-                              first_idx, idx_step, GTS, stage, mask1, h2m, th);
-        // the accumulator tiles: fetched here, ~300 instructions (the spline backward) ahead of their first use;
-        // any earlier and the 15 registers they occupy push the kernel past 256 (2 waves per SIMD)
-        if constexpr (WGRAD) pre = wgrad_prefetch(gw, d);
+        const float* wflat = a.prep + hdr_floats(GK) + l * a.per_layer + off;
+        const CondGeom G{(int)((to_base ? co : cu) - lds) - (int)threadIdx.x + wbase, C_OFF + wbase, ONES_OFF, first_idx,
+                         idx_step, GROW, d};
+        float h1m[4][4], h2m[4][4];
+        cond_fwd_mfma(lds, G, cw, h1m, h2m, th);
+        // fetched here, the spline backward ahead of their first use: the first data-backprop operand and the first
+        // accumulator tile of the weight gradient (the others at the start of cond_bwd_mfma)
+        const int o_wo = (1 + d) * 16 + 16 + 256 + 16;
+        const f4 Ao = cond_weight_T(wflat + o_wo);
+        WgradAcc pre_o;
+        if constexpr (WGRAD) pre_o = wgrad_fetch(gw + o_wo, 16, gw + o_wo + 256);
+        __builtin_amdgcn_sched_barrier(0);
         float vb;
-        if (to_base) vb = cond_spline_bwd<GK, false, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
+        if (to_base) vb = cond_spline_bwd<GK, false, FAST>(th, cu[i * GROW], co[i * GROW], ao[i * GROW], ld_bar, a.sc, tb);
         // (base -> data: the output is formed again inside, in the bin the backward selects -- next to a knot the stashed
         // one can lie a rounding outside that bin, and 1 / f' of a clipped position is garbage: soak_vjp_case_1_16.log)
-        else vb = cond_spline_bwd<GK, true, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb, nullptr, nullptr,
+        else vb = cond_spline_bwd<GK, true, FAST>(th, cu[i * GROW], co[i * GROW], ao[i * GROW], ld_bar, a.sc, tb, nullptr, nullptr,
                                                   nullptr, true);
-        au[i * GTS] += vb;
-        conditioner_bwd_mfma<WGRAD>(a.prep + hdr_floats(GK) + l * a.per_layer + off, w, d, c, to_base ? co : cu,
-                                    first_idx, idx_step, GTS, mask1, h2m, tb, to_base ? ao : au, gw, stage, pre);
+        au[i * GROW] += vb;
+        // the next conditioner's recomputation weights: covered by this one's backward
+        if (d > 1) cw = cond_weights(reinterpret_cast<const f4*>(a.wq + l * a.per_layer_q + offq - cond_floats_mfma(d - 1, 2)),
+                                     wflat - cond_floats(d - 1, 16, 2, GP), d - 1);
+        cond_bwd_mfma<WGRAD>(lds, G, (int)((to_base ? Aout : Ain) - lds) + wbase, wflat, Ao, h1m, h2m, tb, gw, stage, pre_o);
       } else {
+        uniform_ptr w = weights + l * a.per_layer + off;
         if constexpr (WGRAD) pre = wgrad_prefetch(gw, d);
         float h1[16], h2[16];
-        conditioner_keep(w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, h1, h2, th);
+        conditioner_keep(w, d, c, to_base ? co : cu, first_idx, idx_step, GROW, h1, h2, th);
         float vb;
-        if (to_base) vb = cond_spline_bwd<GK, false, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb);
-        else vb = cond_spline_bwd<GK, true, FAST>(th, cu[i * GTS], co[i * GTS], ao[i * GTS], ld_bar, a.sc, tb, nullptr, nullptr,
+        if (to_base) vb = cond_spline_bwd<GK, false, FAST>(th, cu[i * GROW], co[i * GROW], ao[i * GROW], ld_bar, a.sc, tb);
+        else vb = cond_spline_bwd<GK, true, FAST>(th, cu[i * GROW], co[i * GROW], ao[i * GROW], ld_bar, a.sc, tb, nullptr, nullptr,
                                                   nullptr, true);
-        au[i * GTS] += vb;
-        conditioner_bwd<WGRAD>(w, d, c, to_base ? co : cu, first_idx, idx_step, GTS, h1, h2, tb, to_base ? ao : au,
-                               gw, stage ? stage + 16 * STG : nullptr, pre);
+        au[i * GROW] += vb;
+        conditioner_bwd<WGRAD>(w, d, c, to_base ? co : cu, first_idx, idx_step, GROW, h1, h2, tb, to_base ? ao : au,
+                               gw, stage, pre);
       }
     }
     float vb0;
-    if (to_base) vb0 = table_spline_bwd<GK, false, FAST>(tab, cu[first_idx * GTS], co[first_idx * GTS], ao[first_idx * GTS],
+    if (to_base) vb0 = table_spline_bwd<GK, false, FAST>(tab, cu[first_idx * GROW], co[first_idx * GROW], ao[first_idx * GROW],
                                                          ld_bar, a.sc, fa.Wb, fa.Hb, fa.Db);
-    else vb0 = table_spline_bwd<GK, true, FAST>(tab, cu[first_idx * GTS], co[first_idx * GTS], ao[first_idx * GTS],
+    else vb0 = table_spline_bwd<GK, true, FAST>(tab, cu[first_idx * GROW], co[first_idx * GROW], ao[first_idx * GROW],
                                                 ld_bar, a.sc, fa.Wb, fa.Hb, fa.Db);
-    au[first_idx * GTS] += vb0;
-    float* t = Ao; Ao = Au; Au = t;
+    au[first_idx * GROW] += vb0;
+    float* t = Aout; Aout = Ain; Ain = t;
   }
-  return Ao;
+  return Aout;
 }
 
 __device__ __forceinline__ float base_lp(const float* col, int D) {
   float b = 0.0f;
-  for (int d = 0; d < D; ++d) { const float x = col[d * GTS]; b = fmaf(-0.5f * x, x, b); }
+  for (int d = 0; d < D; ++d) { const float x = col[d * GROW]; b = fmaf(-0.5f * x, x, b); }
   return b - (float)(D * HALF_LOG_2PI);
 }
 
@@ -213,26 +237,26 @@ __device__ __forceinline__ float base_lp(const float* col, int D) {
 __device__ __forceinline__ void drift_vjp(const float* r3, const float* ub, float* r3b, int D, int subtype, float a) {
   switch (subtype) {
     case CNF_DRIFT_SMILE: {
-      const float x = r3[0], y = r3[GTS], q = x * x + y * y - 4.0f, u0 = ub[0], u1 = ub[GTS];
+      const float x = r3[0], y = r3[GROW], q = x * x + y * y - 4.0f, u0 = ub[0], u1 = ub[GROW];
       r3b[0] -= u0 * (-a * (q + 2.0f * x * x)) + u1 * (-a * 2.0f * x * y);
-      r3b[GTS] -= u0 * (-a * 2.0f * x * y) + u1 * (-a * (q + 2.0f * y * y + 2.0f));
+      r3b[GROW] -= u0 * (-a * 2.0f * x * y) + u1 * (-a * (q + 2.0f * y * y + 2.0f));
       break;
     }
     case CNF_DRIFT_NONGRADIENT: {
-      const float u0 = ub[0], u1 = ub[GTS];
+      const float u0 = ub[0], u1 = ub[GROW];
       r3b[0] -= u0 * (-a) + u1 * 0.5f;
-      r3b[GTS] -= u0 * (-0.5f) + u1 * (-a);
+      r3b[GROW] -= u0 * (-0.5f) + u1 * (-a);
       break;
     }
     case CNF_DRIFT_LORENZ: {
-      const float x = r3[0], y = r3[GTS], z = r3[2 * GTS], u0 = ub[0], u1 = ub[GTS], u2 = ub[2 * GTS];
+      const float x = r3[0], y = r3[GROW], z = r3[2 * GROW], u0 = ub[0], u1 = ub[GROW], u2 = ub[2 * GROW];
       r3b[0] -= u0 * -10.0f + u1 * (28.0f - 9.0f * z) + u2 * 9.0f * y;
-      r3b[GTS] -= u0 * 10.0f - u1 + u2 * 9.0f * x;
-      r3b[2 * GTS] -= u1 * (-9.0f * x) + u2 * (-8.0f / 3.0f);
+      r3b[GROW] -= u0 * 10.0f - u1 + u2 * 9.0f * x;
+      r3b[2 * GROW] -= u1 * (-9.0f * x) + u2 * (-8.0f / 3.0f);
       break;
     }
     default:
-      for (int d = 0; d < D; ++d) r3b[d * GTS] += a * ub[d * GTS];
+      for (int d = 0; d < D; ++d) r3b[d * GROW] += a * ub[d * GROW];
   }
 }
 
@@ -251,13 +275,12 @@ enum Role {
 
 // DFIX > 0: the event dimension as a compile-time constant (dim 2: the reference's main configurations)
 template <bool FAST, int DFIX = 0>
-__global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void grad_kernel(const GradArgs a) {
+__global__ __launch_bounds__(GTS_MAX, 2) void grad_kernel(const GradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HDR = hdr_floats(GK);
   const int D = DFIX ? DFIX : a.m.D, L = a.m.L;
-  const int DT = D * GTS;
-  float* tab = lds;
-  float* Nn = lds + HDR;
+  const int DT = D * GROW;
+  float* Nn = lds + PRE_FLOATS;
   float* St = Nn + DT;                  // (L+1) stashes
   float* Aa = St + (L + 1) * DT;
   float* Ab = Aa + DT;
@@ -266,7 +289,8 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void grad_kernel(const
   float* R3b = R3 + DT;
   float* Ub = R3b + DT;
   float* stage = Ub + DT + (threadIdx.x >> 6) * STAGE_FLOATS;
-  for (int i = threadIdx.x; i < HDR; i += GTS) tab[i] = a.m.prep[i];
+  for (int i = threadIdx.x; i < HDR; i += GTS) lds[i] = a.m.prep[i];
+  tile_consts(lds);
   const int tid = threadIdx.x;
   const int kind = a.spec.kind;
   float* gslab = a.slabs + ((int64_t)blockIdx.x * (GTS >> 6) + (tid >> 6)) * a.n_params;
@@ -321,19 +345,19 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void grad_kernel(const
                     : ((role == R_R2 || role == R_R2B) ? t + 0.5f * dt : t);
       // ---- pass input
       if (role == R_LPP || role == R_LPM || role == R_LPPB) {
-        for (int e = 0; e < D; ++e) s0[e * GTS] = r3[e * GTS];
-        s0[dd * GTS] += role == R_LPM ? -0.5f * dx : 0.5f * dx;
+        for (int e = 0; e < D; ++e) s0[e * GROW] = r3[e * GROW];
+        s0[dd * GROW] += role == R_LPM ? -0.5f * dx : 0.5f * dx;
       } else {
-        for (int e = 0; e < D; ++e) s0[e * GTS] = n_[e * GTS];
+        for (int e = 0; e < D; ++e) s0[e * GROW] = n_[e * GROW];
       }
-      const float ldsum = pass_fwd_stash<FAST, DFIX>(a.m, tab, St, c, to_base);
+      const float ldsum = pass_fwd_stash<FAST, DFIX>(a.m, lds, St, c, to_base);
       // ---- act on the result, prepare the seeds
       bool do_bwd = false;
       float ld_bar = 0.0f;
       switch (role) {
         case R_NEG: {
           lossv = -(base_lp(sL, D) + ldsum);
-          for (int e = 0; e < D; ++e) aa[e * GTS] = sc * sL[e * GTS];      // d(-lp)/dx_e = x_e
+          for (int e = 0; e < D; ++e) aa[e * GROW] = sc * sL[e * GROW];      // d(-lp)/dx_e = x_e
           ld_bar = -sc; do_bwd = true;
           break;
         }
@@ -341,18 +365,18 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void grad_kernel(const
           const float pa = a.spec.a;
           if (a.spec.subtype == CNF_POT_DOUBLE_WELL) {
             float sm = 0.0f, sp = 0.0f;
-            for (int e = 0; e < D; ++e) { const float r = sL[e * GTS]; sm = fmaf(r - pa, r - pa, sm); sp = fmaf(r + pa, r + pa, sp); }
+            for (int e = 0; e < D; ++e) { const float r = sL[e * GROW]; sm = fmaf(r - pa, r - pa, sm); sp = fmaf(r + pa, r + pa, sp); }
             lossv = sm * sp * 0.25f;
-            for (int e = 0; e < D; ++e) { const float r = sL[e * GTS]; aa[e * GTS] = sc * 0.5f * ((r - pa) * sp + (r + pa) * sm); }
+            for (int e = 0; e < D; ++e) { const float r = sL[e * GROW]; aa[e * GROW] = sc * 0.5f * ((r - pa) * sp + (r + pa) * sm); }
           } else {
             float s2 = 0.0f;
-            for (int e = 0; e < D; ++e) { const float r = sL[e * GTS]; s2 = fmaf(r, r, s2); }
+            for (int e = 0; e < D; ++e) { const float r = sL[e * GROW]; s2 = fmaf(r, r, s2); }
             if (a.spec.subtype == CNF_POT_OBSTACLE) {
               lossv = 50.0f * expf(-0.5f * s2);
-              for (int e = 0; e < D; ++e) aa[e * GTS] = -sc * lossv * sL[e * GTS];
+              for (int e = 0; e < D; ++e) aa[e * GROW] = -sc * lossv * sL[e * GROW];
             } else {
               lossv = 0.5f * s2;
-              for (int e = 0; e < D; ++e) aa[e * GTS] = sc * sL[e * GTS];
+              for (int e = 0; e < D; ++e) aa[e * GROW] = sc * sL[e * GROW];
             }
           }
           do_bwd = true;
@@ -361,7 +385,7 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void grad_kernel(const
         case R_RKL: {
           const float lp = base_lp(n_, D) - ldsum;
           float s2 = 0.0f;
-          for (int e = 0; e < D; ++e) { const float r = sL[e * GTS]; s2 = fmaf(r, r, s2); }
+          for (int e = 0; e < D; ++e) { const float r = sL[e * GROW]; s2 = fmaf(r, r, s2); }
           const float Tt = a.spec.T, vs = 2.0f / a.spec.beta * (Tt + 1.0f), vt = 2.0f / a.spec.beta;
           const float ws = (Tt - t) / Tt, wt = t / Tt;
           const float ls = -0.5f * D * logf(6.283185307179586f * vs), lt = -0.5f * D * logf(6.283185307179586f * vt);
@@ -370,68 +394,68 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void grad_kernel(const
           const float es = expf(as - mx) * ws, et = expf(at - mx) * wt;
           lossv = lp - (mx + logf(es + et));
           const float g = (es / vs + et / vt) / (es + et);      // -d logmix / d y_e = g * y_e
-          for (int e = 0; e < D; ++e) aa[e * GTS] = sc * g * sL[e * GTS];
+          for (int e = 0; e < D; ++e) aa[e * GROW] = sc * g * sL[e * GROW];
           ld_bar = -sc; do_bwd = true;
           break;
         }
         case R_R1:
-          for (int e = 0; e < D; ++e) v_[e * GTS] = sL[e * GTS];
+          for (int e = 0; e < D; ++e) v_[e * GROW] = sL[e * GROW];
           break;
         case R_R2: {
           const float inv_dt = 1.0f / dt;
-          for (int e = 0; e < D; ++e) v_[e * GTS] = (sL[e * GTS] - v_[e * GTS]) * inv_dt;      // velocity
+          for (int e = 0; e < D; ++e) v_[e * GROW] = (sL[e * GROW] - v_[e * GROW]) * inv_dt;      // velocity
           if (kind == CNF_TERM_KINETIC) {
             for (int e = 0; e < D; ++e) {
-              const float v = v_[e * GTS];
+              const float v = v_[e * GROW];
               lossv = fmaf(v, v, lossv);
-              ub[e * GTS] = 2.0f * sc * v;
-              aa[e * GTS] = ub[e * GTS] * inv_dt;
+              ub[e * GROW] = 2.0f * sc * v;
+              aa[e * GROW] = ub[e * GROW] * inv_dt;
             }
             do_bwd = true;                          // the r2 stash is live
           }
           break;
         }
         case R_R3:
-          for (int e = 0; e < D; ++e) { r3[e * GTS] = sL[e * GTS]; r3b[e * GTS] = 0.0f; }
+          for (int e = 0; e < D; ++e) { r3[e * GROW] = sL[e * GROW]; r3b[e * GROW] = 0.0f; }
           break;
         case R_LPP:
           lp_plus = base_lp(sL, D) + ldsum;
           break;
         case R_LPM: {
           const float lp_minus = base_lp(sL, D) + ldsum;
-          float u = fmaf((lp_plus - lp_minus) / dx, coef, v_[dd * GTS]);
-          if (kind == CNF_TERM_FLOW_MATCHING) u -= drift_of<float>(r3, dd, D, GTS, a.spec.subtype, a.spec.a);
+          float u = fmaf((lp_plus - lp_minus) / dx, coef, v_[dd * GROW]);
+          if (kind == CNF_TERM_FLOW_MATCHING) u -= drift_of<float>(r3, dd, D, GROW, a.spec.subtype, a.spec.a);
           lossv = fmaf(u, u, lossv);
           ubar = 2.0f * sc * u;
-          ub[dd * GTS] = ubar;
+          ub[dd * GROW] = ubar;
           ld_bar = -ubar * coef / dx;                // d u / d lp_minus
-          for (int e = 0; e < D; ++e) aa[e * GTS] = -ld_bar * sL[e * GTS];     // d base / d x_e = -x_e
+          for (int e = 0; e < D; ++e) aa[e * GROW] = -ld_bar * sL[e * GROW];     // d base / d x_e = -x_e
           do_bwd = true;
           break;
         }
         case R_LPPB:
           ld_bar = ubar * coef / dx;
-          for (int e = 0; e < D; ++e) aa[e * GTS] = -ld_bar * sL[e * GTS];
+          for (int e = 0; e < D; ++e) aa[e * GROW] = -ld_bar * sL[e * GROW];
           do_bwd = true;
           break;
         case R_R3B:
           if (kind == CNF_TERM_FLOW_MATCHING) drift_vjp(r3, ub, r3b, D, a.spec.subtype, a.spec.a);
-          for (int e = 0; e < D; ++e) aa[e * GTS] = r3b[e * GTS];
+          for (int e = 0; e < D; ++e) aa[e * GROW] = r3b[e * GROW];
           do_bwd = true;
           break;
         case R_R2B:
-          for (int e = 0; e < D; ++e) aa[e * GTS] = ub[e * GTS] / dt;
+          for (int e = 0; e < D; ++e) aa[e * GROW] = ub[e * GROW] / dt;
           do_bwd = true;
           break;
         default:   // R_R1B
-          for (int e = 0; e < D; ++e) aa[e * GTS] = -ub[e * GTS] / dt;
+          for (int e = 0; e < D; ++e) aa[e * GROW] = -ub[e * GROW] / dt;
           do_bwd = true;
           break;
       }
       if (do_bwd) {
-        const float* ain = pass_bwd<FAST, true, DFIX>(a.m, tab, St, Aa, Ab, ld_bar, c, to_base, gslab, stage, fa) + tid;
+        const float* ain = pass_bwd<FAST, true, DFIX>(a.m, lds, St, Aa, Ab, ld_bar, c, to_base, gslab, stage, fa) + tid;
         if (role == R_LPM || role == R_LPPB)
-          for (int e = 0; e < D; ++e) r3b[e * GTS] += ain[e * GTS];
+          for (int e = 0; e < D; ++e) r3b[e * GROW] += ain[e * GROW];
       }
     }
     float part = valid ? lossv : 0.0f;
@@ -487,18 +511,18 @@ struct VjpArgs {
 // WGRAD=true additionally accumulates the parameter gradient of the pass (the
 // backward of a differentiable flow op: cnf_pass_vjp).
 template <bool FAST, bool WGRAD, int DFIX = 0>
-__global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void vjp_kernel(const VjpArgs a) {
+__global__ __launch_bounds__(GTS_MAX, 2) void vjp_kernel(const VjpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int HDR = hdr_floats(GK);
-  const int D = DFIX ? DFIX : a.m.D, L = a.m.L, DT = D * GTS;
-  float* tab = lds;
-  float* St = lds + HDR;
+  const int D = DFIX ? DFIX : a.m.D, L = a.m.L, DT = D * GROW;
+  float* St = lds + PRE_FLOATS;
   float* Aa = St + (L + 1) * DT;
   float* Ab = Aa + DT;
-  float* stage = Ab + DT + (threadIdx.x >> 6) * STAGE_FLOATS;       // (WGRAD = false: only the h1 region is touched)
+  float* stage = Ab + DT + (threadIdx.x >> 6) * STAGE_FLOATS;       // (WGRAD = false: nothing is staged)
   float* gslab = WGRAD ? a.slabs + ((int64_t)blockIdx.x * (GTS >> 6) + (threadIdx.x >> 6)) * a.n_params : nullptr;
   if (WGRAD) slab_clear(gslab, a.n_params, threadIdx.x & 63);
-  for (int i = threadIdx.x; i < HDR; i += GTS) tab[i] = a.m.prep[i];
+  for (int i = threadIdx.x; i < HDR; i += GTS) lds[i] = a.m.prep[i];
+  tile_consts(lds);
   const int tid = threadIdx.x;
   FirstAcc fa;      // WGRAD=false: written, never read: removed by the compiler
 #pragma unroll
@@ -520,8 +544,8 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void vjp_kernel(const 
       for (int e = 0; e < D; ++e) {
         float v = valid ? a.pts[ib * D + e] : 0.0f;
         if (e == dd) v += (k & 1) ? -a.fd_h : a.fd_h;
-        St[e * GTS + tid] = v;
-        Aa[e * GTS + tid] = 0.0f;
+        St[e * GROW + tid] = v;
+        Aa[e * GROW + tid] = 0.0f;
       }
       const int64_t n_base = a.B / a.fd2;
       c = valid ? a.c[a.c_block >= n_base ? 0 : ib / a.c_block] : 0.0f;
@@ -534,12 +558,12 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void vjp_kernel(const 
       ld_bar = (a.ldbar && i < a.B) ? a.ldbar[i] : 0.0f;
     }
     __syncthreads();
-    pass_fwd_stash<FAST, DFIX>(a.m, tab, St, c, a.to_base != 0);
+    pass_fwd_stash<FAST, DFIX>(a.m, lds, St, c, a.to_base != 0);
     if (a.fd2) {       // log_prob = sum -x^2/2 + ildj: the adjoint of the recovered base point is -ld_bar x
       const float* sL = St + L * DT + tid;
-      for (int e = 0; e < D; ++e) Aa[e * GTS + tid] = -ld_bar * sL[e * GTS];
+      for (int e = 0; e < D; ++e) Aa[e * GROW + tid] = -ld_bar * sL[e * GROW];
     }
-    float* ain = pass_bwd<FAST, WGRAD, DFIX>(a.m, tab, St, Aa, Ab, ld_bar, c, a.to_base != 0, gslab, stage, fa);
+    float* ain = pass_bwd<FAST, WGRAD, DFIX>(a.m, lds, St, Aa, Ab, ld_bar, c, a.to_base != 0, gslab, stage, fa);
     __syncthreads();
     if (a.fd2) {       // xbar[i, e] = sum over the fd2 evaluation points of base point i (fixed order: deterministic)
       if (a.xbar) {
@@ -549,7 +573,7 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void vjp_kernel(const 
           const int il = idx / D, e = idx - il * D;
           if (first_base + il < n_base) {
             float sum = 0.0f;
-            for (int k = 0; k < a.fd2; ++k) sum += ain[e * GTS + il * a.fd2 + k];
+            for (int k = 0; k < a.fd2; ++k) sum += ain[e * GROW + il * a.fd2 + k];
             a.xbar[(first_base + il) * D + e] = sum;
           }
         }
@@ -559,7 +583,7 @@ __global__ __launch_bounds__(GTS_MAX, CNF_BWD_MIN_BLOCKS) void vjp_kernel(const 
       const int n_el = (int)(a.B - tile_start < GTS ? a.B - tile_start : GTS) * D;
       for (int e = tid; e < GTS * D; e += GTS) {
         const int s = a.div_magic ? (int)__umulhi((uint32_t)e, a.div_magic) : e, d = e - s * D;
-        if (e < n_el) a.xbar[base + e] = ain[d * GTS + s];
+        if (e < n_el) a.xbar[base + e] = ain[d * GROW + s];
       }
     }
   }
@@ -1320,12 +1344,13 @@ using namespace cnf;
 
 #undef GTS
 static size_t grad_lds_bytes(int D, int L, int ts = GTS_MAX) {
-  // tab + noise + (L+1) stashes + 2 adjoint buffers + velocity, r3, r3_bar, u_bar + one MFMA staging area per wave
-  return (size_t)(hdr_floats(GK) + D * ts * (1 + (L + 1) + 6) + (ts / 64) * STAGE_FLOATS) * sizeof(float);
+  // table, ones / zeros, condition column + noise + (L+1) stashes + 2 adjoint buffers + velocity, r3, r3_bar, u_bar
+  // (rows of ts + 4 floats) + one MFMA staging area per wave
+  return (size_t)(hdr_floats(GK) + 64 + (ts + 4) + D * (ts + 4) * (1 + (L + 1) + 6) + (ts / 64) * STAGE_FLOATS) * sizeof(float);
 }
 static size_t vjp_lds_bytes(int D, int L, int ts, bool wgrad) {
-  (void)wgrad;       // the MFMA recompute stages h1 even without weight gradients
-  return (size_t)(hdr_floats(GK) + D * ts * ((L + 1) + 2) + (ts / 64) * STAGE_FLOATS) * sizeof(float);
+  // (without weight gradients nothing is staged)
+  return (size_t)(hdr_floats(GK) + 64 + (ts + 4) + D * (ts + 4) * ((L + 1) + 2) + (wgrad ? (ts / 64) * STAGE_FLOATS : 0)) * sizeof(float);
 }
 // The tile size (threads per workgroup) that puts the most waves on a CU: LDS allows 160 KB / lds(ts) workgroups
 // of ts / 64 waves; the backward kernels' ~230 VGPRs allow 8 waves (2 per SIMD).  Ties go to the larger tile.
@@ -1375,22 +1400,24 @@ extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const f
   a.B = B; a.n_slices = n_slices; a.pts_slice_stride = pts_shared ? 0 : B;
   a.scale = scale; a.div_magic = m->div_magic;
   const int ts = pick_tile([&](int t) { return grad_lds_bytes(D, L, t); });
-  int64_t grid = ((B + ts - 1) / ts) * n_slices;
-  if (grid > m->grad_max_blocks * 4 / (ts / 64)) grid = m->grad_max_blocks * 4 / (ts / 64);
   const size_t lds = grad_lds_bytes(D, L, ts);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
-  const int64_t n_slabs = grid * (ts / 64);
+  const int64_t n_tiles = ((B + ts - 1) / ts) * n_slices;
+  const int64_t max_grid = m->grad_max_blocks * 4 / (ts / 64);           // (slabs: one per wave)
+  int64_t n_slabs = 0;
+  auto launch = [&](auto kernel) -> bool {
+    if (!ensure_lds(kernel, lds)) return false;
+    int64_t cap = (int64_t)resident_blocks_per_cu(kernel, ts, lds) * m->num_cus;
+    if (cap > max_grid) cap = max_grid;
+    const int64_t grid = balanced_grid(n_tiles, cap);
+    n_slabs = grid * (ts / 64);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    return true;
+  };
   if (m->fast_math) {
-    if (D == 2) {
-      if (!ensure_lds(grad_kernel<true, 2>, lds)) return CNF_ERR_HIP;
-      hipLaunchKernelGGL((grad_kernel<true, 2>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
-    } else {
-      if (!ensure_lds(grad_kernel<true>, lds)) return CNF_ERR_HIP;
-      hipLaunchKernelGGL(grad_kernel<true>, dim3((unsigned)grid), dim3(ts), lds, stream, a);
-    }
+    if (D == 2 ? !launch(grad_kernel<true, 2>) : !launch(grad_kernel<true>)) return CNF_ERR_HIP;
   } else {
-    if (!ensure_lds(grad_kernel<false>, lds)) return CNF_ERR_HIP;
-    hipLaunchKernelGGL(grad_kernel<false>, dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    if (!launch(grad_kernel<false>)) return CNF_ERR_HIP;
   }
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
   const int fb = (int)((m->n_params + 31) / 32);
@@ -1518,32 +1545,27 @@ static int pass_vjp_impl(CnfModel* m, int to_base, const float* pts, const float
   a.fd2 = 0; a.fd_h = 0.f; a.fd_inv_dx = 0.f; a.gbar = nullptr;
   const int D = m->cfg.dim, L = m->cfg.num_layers;
   const int ts = pick_tile([&](int t) { return vjp_lds_bytes(D, L, t, grad != nullptr); });
-  size_t lds = vjp_lds_bytes(D, L, ts, grad != nullptr);
-  int64_t grid = (B + ts - 1) / ts;
+  const size_t lds = vjp_lds_bytes(D, L, ts, grad != nullptr);
+  const int64_t n_tiles = (B + ts - 1) / ts;
+  const int64_t max_grid = grad ? m->grad_max_blocks * 4 / (ts / 64) : (int64_t)1 << 30;
+  int64_t n_slabs = 0;
+  auto launch = [&](auto kernel) -> bool {
+    if (!ensure_lds(kernel, lds)) return false;
+    int64_t cap = (int64_t)resident_blocks_per_cu(kernel, ts, lds) * m->num_cus;
+    if (cap > max_grid) cap = max_grid;
+    const int64_t grid = balanced_grid(n_tiles, cap);
+    n_slabs = grid * (ts / 64);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    return true;
+  };
   if (!grad) {
-    if (grid > (int64_t)m->num_cus * 4 * (GTS_MAX / ts)) grid = (int64_t)m->num_cus * 4 * (GTS_MAX / ts);
-    if (m->fast_math) {
-      if (!ensure_lds(vjp_kernel<true, false>, lds)) return CNF_ERR_UNSUPPORTED;
-      hipLaunchKernelGGL((vjp_kernel<true, false>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
-    } else {
-      if (!ensure_lds(vjp_kernel<false, false>, lds)) return CNF_ERR_UNSUPPORTED;
-      hipLaunchKernelGGL((vjp_kernel<false, false>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
-    }
+    if (m->fast_math ? !launch(vjp_kernel<true, false>) : !launch(vjp_kernel<false, false>)) return CNF_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
   }
-  if (grid > m->grad_max_blocks * 4 / (ts / 64)) grid = m->grad_max_blocks * 4 / (ts / 64);
-  const int64_t n_slabs = grid * (ts / 64);
   if (m->fast_math) {
-    if (D == 2) {
-      if (!ensure_lds(vjp_kernel<true, true, 2>, lds)) return CNF_ERR_UNSUPPORTED;
-      hipLaunchKernelGGL((vjp_kernel<true, true, 2>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
-    } else {
-      if (!ensure_lds(vjp_kernel<true, true>, lds)) return CNF_ERR_UNSUPPORTED;
-      hipLaunchKernelGGL((vjp_kernel<true, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
-    }
+    if (D == 2 ? !launch(vjp_kernel<true, true, 2>) : !launch(vjp_kernel<true, true>)) return CNF_ERR_UNSUPPORTED;
   } else {
-    if (!ensure_lds(vjp_kernel<false, true>, lds)) return CNF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((vjp_kernel<false, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    if (!launch(vjp_kernel<false, true>)) return CNF_ERR_UNSUPPORTED;
   }
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
   const int fb = (int)((m->n_params + 31) / 32);
@@ -1587,20 +1609,22 @@ extern "C" int cnf_logprob_fd_vjp(CnfModel* m, const float* pts, const float* c,
   const size_t lds = vjp_lds_bytes(D, L, ts, true);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
   const int64_t tp = (ts / (2 * D)) * (2 * D);
-  int64_t grid = (a.B + tp - 1) / tp;
-  if (grid > m->grad_max_blocks * 4 / (ts / 64)) grid = m->grad_max_blocks * 4 / (ts / 64);
-  const int64_t n_slabs = grid * (ts / 64);
+  const int64_t n_tiles = (a.B + tp - 1) / tp;
+  const int64_t max_grid = m->grad_max_blocks * 4 / (ts / 64);
+  int64_t n_slabs = 0;
+  auto launch = [&](auto kernel) -> bool {
+    if (!ensure_lds(kernel, lds)) return false;
+    int64_t cap = (int64_t)resident_blocks_per_cu(kernel, ts, lds) * m->num_cus;
+    if (cap > max_grid) cap = max_grid;
+    const int64_t grid = balanced_grid(n_tiles, cap);
+    n_slabs = grid * (ts / 64);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    return true;
+  };
   if (m->fast_math) {
-    if (D == 2) {
-      if (!ensure_lds(vjp_kernel<true, true, 2>, lds)) return CNF_ERR_UNSUPPORTED;
-      hipLaunchKernelGGL((vjp_kernel<true, true, 2>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
-    } else {
-      if (!ensure_lds(vjp_kernel<true, true>, lds)) return CNF_ERR_UNSUPPORTED;
-      hipLaunchKernelGGL((vjp_kernel<true, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
-    }
+    if (D == 2 ? !launch(vjp_kernel<true, true, 2>) : !launch(vjp_kernel<true, true>)) return CNF_ERR_UNSUPPORTED;
   } else {
-    if (!ensure_lds(vjp_kernel<false, true>, lds)) return CNF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((vjp_kernel<false, true>), dim3((unsigned)grid), dim3(ts), lds, stream, a);
+    if (!launch(vjp_kernel<false, true>)) return CNF_ERR_UNSUPPORTED;
   }
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
   const int fb = (int)((m->n_params + 31) / 32);
