@@ -295,7 +295,7 @@ __device__ __forceinline__ void dense_T(uniform_ptr W, const float (&in)[16], fl
 
 // ---------------------------------------------------------------------------
 // dW[i][j] += sum over the wave's 64 samples of a_i * b_j, on the matrix core.
-// `stage` is this wave's LDS staging area (2 x 16 x STG floats).  Sample s goes
+// `stage` is this wave's LDS staging region (16 x STG floats; the two operands pass through it in turn).  Sample s goes
 // to MFMA step n = s & 15, k-slot g = s >> 4.  dW is row-major [rows][16] in
 // this wave's private gradient slab; only rows < n_rows are stored.  If db is
 // non-null the column sums of b are added to db[16].
@@ -319,19 +319,20 @@ __device__ __forceinline__ WgradAcc wgrad_fetch(const float* __restrict__ dW, in
 __device__ __forceinline__ void wgrad_mfma(float* stage, const float (&a)[16], const float (&b)[16],
                                            float* __restrict__ dW, int n_rows, float* __restrict__ db, WgradAcc pre) {
   const int lane = threadIdx.x & 63;
-  float* sa = stage;
-  float* sb = stage + 16 * STG;
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { sa[i * STG + lane] = a[i]; sb[i * STG + lane] = b[i]; }
-  __builtin_amdgcn_wave_barrier();
   const int g = lane >> 4, i = lane & 15;
   f4 av[4], bv[4];
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    av[n] = *reinterpret_cast<const f4*>(sa + i * STG + 16 * g + 4 * n);
-    bv[n] = *reinterpret_cast<const f4*>(sb + i * STG + 16 * g + 4 * n);
-  }
+  for (int r = 0; r < 16; ++r) stage[r * STG + lane] = a[r];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int n = 0; n < 4; ++n) av[n] = *reinterpret_cast<const f4*>(stage + i * STG + 16 * g + 4 * n);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stage[r * STG + lane] = b[r];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int n = 0; n < 4; ++n) bv[n] = *reinterpret_cast<const f4*>(stage + i * STG + 16 * g + 4 * n);
   __builtin_amdgcn_wave_barrier();
   f4 acc = pre.acc;
 #pragma unroll
@@ -429,7 +430,7 @@ __device__ __forceinline__ void stage_m(float* region, const float (&m)[4][4]) {
   }
 }
 
-constexpr int STAGE_FLOATS = 2 * 16 * STG;       // per wave: region 0 [h2, then h1], region 1 [theta_bar, then g2, then g1]
+constexpr int STAGE_FLOATS = 16 * STG;           // per wave: ONE [unit][sample] region, the two operands of a weight-gradient GEMM pass through it in turn
 
 // Conditioner forward (M = 2) on the matrix cores: theta in the lane layout; both hidden activations are handed back
 // in MFMA layout (the backward's ReLU masks are their signs, and they are the operands of its weight-gradient GEMMs).
@@ -491,61 +492,56 @@ __device__ __forceinline__ f4 cond_weight_T(const float* __restrict__ wmat) {
   return *reinterpret_cast<const f4*>(wmat + i * 16 + 4 * g);
 }
 
-// dW += a b^T over the wave's 64 samples from STAGED operands ([unit][sample] regions)
-__device__ __forceinline__ void wgrad_staged(const float* sa, const float* sb, float* __restrict__ dW,
-                                             float* __restrict__ db, WgradAcc pre) {
+// One operand of a weight-gradient GEMM (K = the wave's 64 samples): MFMA-layout values -> the staging region ->
+// the lane's 4 x 16 bytes along the samples of unit i (A and B operands have the same form: lane (g, i), k = sample)
+struct WgradOp { f4 v[4]; };
+__device__ __forceinline__ WgradOp wgrad_operand(float* region, const float (&m)[4][4]) {
   const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
-  f4 av[4], bv[4];
+  __builtin_amdgcn_wave_barrier();
+  stage_m(region, m);
+  __builtin_amdgcn_wave_barrier();
+  WgradOp o;
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    av[n] = *reinterpret_cast<const f4*>(sa + i * STG + 16 * g + 4 * n);
-    bv[n] = *reinterpret_cast<const f4*>(sb + i * STG + 16 * g + 4 * n);
-  }
+  for (int n = 0; n < 4; ++n) o.v[n] = *reinterpret_cast<const f4*>(region + i * STG + 16 * g + 4 * n);
+  __builtin_amdgcn_wave_barrier();
+  return o;
+}
+// ... or straight from the input rows of the conditioner (row k = lane's i; the ones row yields the bias gradient as row d + 1)
+__device__ __forceinline__ WgradOp wgrad_operand_inputs(const float* lds, const CondGeom& G) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+  const float* ra = lds + cond_row_off(G, i) + 16 * g;
+  WgradOp o;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) o.v[n] = *reinterpret_cast<const f4*>(ra + 4 * n);
+  return o;
+}
+
+// dW[rows < n_rows][16] += a b^T over the wave's 64 samples; db (optional) += the column sums of b
+__device__ __forceinline__ void wgrad_apply(const WgradOp& a, const WgradOp& b, float* __restrict__ dW, int n_rows,
+                                            float* __restrict__ db, WgradAcc pre) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
   f4 acc = pre.acc;
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[n][e], bv[n][e], acc, 0, 0, 0);
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[n][e], b.v[n][e], acc, 0, 0, 0);
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) dW[(4 * g + r) * 16 + i] = acc[r];
+  for (int r = 0; r < 4; ++r) if (4 * g + r < n_rows) dW[(4 * g + r) * 16 + i] = acc[r];
   if (db) {
     float sum = 0.0f;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) sum += (bv[n][0] + bv[n][1]) + (bv[n][2] + bv[n][3]);
+    for (int n = 0; n < 4; ++n) sum += (b.v[n][0] + b.v[n][1]) + (b.v[n][2] + b.v[n][3]);
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     if (g == 0) db[i] = pre.bias + sum;
   }
 }
 
-// The first layer's weight gradient: dW0pad[k][j] += sum_samples in_k g1_j, the A operand read straight from the
-// input rows (row k = lane's i; the ones row yields the bias gradient as row d + 1), the B operand staged.
-__device__ __forceinline__ void wgrad_inputs(const float* lds, const CondGeom& G, const float* sb,
-                                             float* __restrict__ dW, WgradAcc pre) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
-  const float* ra = lds + cond_row_off(G, i) + 16 * g;
-  f4 av[4], bv[4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    av[n] = *reinterpret_cast<const f4*>(ra + 4 * n);
-    bv[n] = *reinterpret_cast<const f4*>(sb + i * STG + 16 * g + 4 * n);
-  }
-  f4 acc = pre.acc;
-#pragma unroll
-  for (int n = 0; n < 4; ++n) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[n][e], bv[n][e], acc, 0, 0, 0);
-  }
-  const int n_rows = G.d + 2;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) if (4 * g + r < n_rows) dW[(4 * g + r) * 16 + i] = acc[r];
-}
-
 // Conditioner backward on the matrix cores.  h1m / h2m: the hidden activations of cond_fwd_mfma, tb: theta_bar in the
 // lane layout, adj_off: LDS offset (wave's first sample, row 0) of the buffer that receives the adjoints of the
-// conditioning inputs, gw: this conditioner's block of the wave's gradient slab.  Staging (two [unit][sample] regions
-// per wave): h2 | theta_bar -> dWo;  h1 | g2 -> dW1;  (input rows) | g1 -> dW0.
+// conditioning inputs, gw: this conditioner's block of the wave's gradient slab.  Weight gradients: h2 x theta_bar -> dWo,
+// h1 x g2 -> dW1, (input rows) x g1 -> dW0, each operand through the wave's one staging region.
 template <bool WGRAD = true>
 __device__ __forceinline__ void cond_bwd_mfma(float* lds, const CondGeom& G, int adj_off, const float* __restrict__ wflat,
                                               f4 Ao, const float (&h1m)[4][4], const float (&h2m)[4][4],
@@ -553,8 +549,6 @@ __device__ __forceinline__ void cond_bwd_mfma(float* lds, const CondGeom& G, int
   const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
   const int d = G.d;
   const int o_b0 = (1 + d) * 16, o_w1 = o_b0 + 16, o_b1 = o_w1 + 256, o_wo = o_b1 + 16, o_bo = o_wo + 256;
-  float* sa = stage;
-  float* sb = stage + 16 * STG;
   const f4 A1 = cond_weight_T(wflat + o_w1), A0 = cond_weight_T(wflat);       // (A0: rows beyond d give results nobody reads)
   [[maybe_unused]] WgradAcc pre_h, pre_f;
   if constexpr (WGRAD) { pre_h = wgrad_fetch(gw + o_w1, 16, gw + o_b1); pre_f = wgrad_fetch(gw, d + 2, nullptr); }
@@ -562,11 +556,8 @@ __device__ __forceinline__ void cond_bwd_mfma(float* lds, const CondGeom& G, int
   float tbm[4][4];
   to_mfma_layout(tb, tbm);
   if constexpr (WGRAD) {
-    __builtin_amdgcn_wave_barrier();
-    stage_m(sa, h2m);
-    stage_m(sb, tbm);
-    __builtin_amdgcn_wave_barrier();
-    wgrad_staged(sa, sb, gw + o_wo, gw + o_bo, pre_o);
+    const WgradOp oa = wgrad_operand(stage, h2m), ob = wgrad_operand(stage, tbm);
+    wgrad_apply(oa, ob, gw + o_wo, 16, gw + o_bo, pre_o);
   }
   float g2m[4][4];
   {
@@ -585,11 +576,8 @@ __device__ __forceinline__ void cond_bwd_mfma(float* lds, const CondGeom& G, int
     }
   }
   if constexpr (WGRAD) {
-    __builtin_amdgcn_wave_barrier();
-    stage_m(sa, h1m);
-    stage_m(sb, g2m);
-    __builtin_amdgcn_wave_barrier();
-    wgrad_staged(sa, sb, gw + o_w1, gw + o_b1, pre_h);
+    const WgradOp oa = wgrad_operand(stage, h1m), ob = wgrad_operand(stage, g2m);
+    wgrad_apply(oa, ob, gw + o_w1, 16, gw + o_b1, pre_h);
   }
   float g1m[4][4];
   {
@@ -608,10 +596,8 @@ __device__ __forceinline__ void cond_bwd_mfma(float* lds, const CondGeom& G, int
     }
   }
   if constexpr (WGRAD) {
-    __builtin_amdgcn_wave_barrier();
-    stage_m(sb, g1m);
-    __builtin_amdgcn_wave_barrier();
-    wgrad_inputs(lds, G, sb, gw, pre_f);
+    const WgradOp oa = wgrad_operand_inputs(lds, G), ob = wgrad_operand(stage, g1m);
+    wgrad_apply(oa, ob, gw, d + 2, nullptr, pre_f);
   }
   // adjoints of the conditioning inputs: row k = 4g + r of W0 g1 belongs to input k (1 .. d); every (input, sample)
   // has exactly one owner lane-register, so the accumulation is a plain read-modify-write
