@@ -262,6 +262,12 @@ def _score_terms_unfused(ctx, conds, batch_size, dt, dx, coef_score, loss_coef, 
   z3 = z.repeat(3 * S, 1)                                     # the same draw for every slice and condition
   want = ctx.grad is not None
   r, _ = be.forward_logdet(z3, c3, want_logdet=False)
+  if want and drift in (-1, _capi.DRIFTS["ou"]) and hasattr(be, "score_fd_vjp"):
+    # value AND backward of the score term in one launch: the kernel that differentiates the 2 D evaluation points
+    # forms the score from its own forward passes (no separate forward launch over them)
+    sums, rbar = be.score_fd_vjp(r, tt, count, dt, dx, coef_score, drift, a, loss_coef, ctx.grad)
+    be.pass_vjp(z3, c3, rbar, None, False, grad=ctx.grad, want_xbar=False)
+    return sums
   r3 = r[2 * n:]
   score = be.logprob_fd(r3, tt, dx)
   sums, rbar, sbar = be.score_residual(r, score, count, dt, coef_score, drift, a, loss_coef, want)

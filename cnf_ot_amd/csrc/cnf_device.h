@@ -1184,13 +1184,13 @@ __device__ __forceinline__ void conditioner_mfma(const f4* __restrict__ wq, int 
 }
 
 // floats of one conditioner's MFMA-layout block: (1+d) W0 rows, b0, M x {A, bias}, 64 lanes x 4
-__host__ __device__ inline int64_t cond_floats_mfma(int d, int M) { return 256 * (int64_t)((1 + d) + 1 + 2 * M); }
+__host__ __device__ constexpr int64_t cond_floats_mfma(int d, int M) { return 256 * (int64_t)((1 + d) + 1 + 2 * M); }
 
 // floats of one conditioner whose first linear layer has `rows` inputs
-__host__ __device__ inline int64_t cond_floats_rows(int rows, int H, int M, int P) {
+__host__ __device__ constexpr int64_t cond_floats_rows(int rows, int H, int M, int P) {
   return (int64_t)rows * H + H + (int64_t)(M - 1) * (H * H + H) + (int64_t)H * P + P;
 }
-__host__ __device__ inline int64_t cond_floats(int d, int H, int M, int P) { return cond_floats_rows(1 + d, H, M, P); }
+__host__ __device__ constexpr int64_t cond_floats(int d, int H, int M, int P) { return cond_floats_rows(1 + d, H, M, P); }
 // periodized (flows.py:58-64): the MLP sees [sin(c, v), cos(c, v)]: 2 (1 + d) rows
 __host__ __device__ inline int64_t cond_floats_p(int d, int H, int M, int P, bool periodic) {
   return cond_floats_rows((periodic ? 2 : 1) * (1 + d), H, M, P);

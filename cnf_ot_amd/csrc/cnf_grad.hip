@@ -74,11 +74,14 @@ __device__ __forceinline__ void tile_load1(const float* __restrict__ g, float* U
   }
 }
 
-__device__ __forceinline__ int64_t cond_prefix(int d) {      // floats of conditioners 1..d-1 (H=16, M=2, P=16)
-  int64_t o = 0;
-  for (int dd = 1; dd < d; ++dd) o += cond_floats(dd, 16, 2, 16);
-  return o;
-}
+// Offsets inside a flow layer's conditioners in 32-bit closed form (H = 16, M = 2, P = 16): conditioner d has
+// cond_floats(d) = 16 d + 576 flat weights and cond_floats_mfma(d, 2) = 256 (d + 6) MFMA-layout floats (64-bit loops
+// over d here cost ~130 scalar instructions per layer and a dozen scalar registers spilled to vector lanes)
+__device__ __forceinline__ int cond_size(int d) { return 16 * d + 576; }
+__device__ __forceinline__ int cond_size_q(int d) { return 256 * (d + 6); }
+__device__ __forceinline__ int cond_prefix(int d) { return (d - 1) * (8 * d + 576); }          // conditioners 1 .. d-1
+__device__ __forceinline__ int cond_prefix_q(int d) { return (d - 1) * (128 * d + 1536); }
+static_assert(cond_floats(3, 16, 2, 16) == 16 * 3 + 576 && cond_floats_mfma(3, 2) == 256 * (3 + 6), "conditioner sizes");
 
 // forward of one pass with every layer input kept: St[s] is the input of step s
 // (St[0] filled by the caller), St[L] the result.  Returns the log-det sum.
@@ -101,9 +104,9 @@ __device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, float* lds, 
     const int first_idx = odd ? D - 1 : 0, idx_step = odd ? -1 : 1;
     const float* cu = St + s * D * GROW + threadIdx.x;
     float* co = St + (s + 1) * D * GROW + threadIdx.x;
-    uniform_ptr w = weights + l * a.per_layer;
-    [[maybe_unused]] const float* wflat = a.prep + hdr_floats(GK) + l * a.per_layer;
-    [[maybe_unused]] const float* wq = a.wq + l * a.per_layer_q;
+    uniform_ptr w = weights + l * (int)a.per_layer;
+    [[maybe_unused]] const float* wflat = a.prep + hdr_floats(GK) + l * (int)a.per_layer;
+    [[maybe_unused]] const float* wq = a.wq + l * (int)a.per_layer_q;
     [[maybe_unused]] CondW cw;         // the NEXT conditioner's weights: one conditioner ahead (cnf_backward.h)
     if constexpr (FAST) { if (D > 1) cw = cond_weights(reinterpret_cast<const f4*>(wq), wflat, 1); __builtin_amdgcn_sched_barrier(0); }
     float o, ld;
@@ -118,15 +121,15 @@ __device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, float* lds, 
         const CondGeom G{(int)((to_base ? co : cu) - lds) - (int)threadIdx.x + wbase, C_OFF + wbase, ONES_OFF, first_idx,
                          idx_step, GROW, d};
         const CondW cur = cw;
-        wq += cond_floats_mfma(d, 2);
-        wflat += cond_floats(d, 16, 2, GP);
+        wq += cond_size_q(d);
+        wflat += cond_size(d);
         if (d + 1 < D) cw = cond_weights(reinterpret_cast<const f4*>(wq), wflat, d + 1);
         __builtin_amdgcn_sched_barrier(0);
         float h1m[4][4], h2m[4][4];
         cond_fwd_mfma(lds, G, cur, h1m, h2m, th);
       } else {
         conditioner<16, GP, float>(w, d, 2, c, to_base ? co : cu, first_idx, idx_step, GROW, th);
-        w += cond_floats(d, 16, 2, GP);
+        w += cond_size(d);
       }
       if (to_base) cond_spline<GK, false, FAST, float>(th, cu[i * GROW], a.sc, o, ld);
       else cond_spline<GK, true, FAST, float>(th, cu[i * GROW], a.sc, o, ld);
@@ -160,26 +163,26 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, float* lds, const
     float* ao = Aout + threadIdx.x;
     float* au = Ain + threadIdx.x;
     for (int d = 0; d < D; ++d) au[d * GROW] = 0.0f;
-    int64_t off = cond_prefix(D);                     // end of this layer's conditioners
-    [[maybe_unused]] int64_t offq = 0;                 // the same in the MFMA-layout weights
+    const int lay = l * (int)a.per_layer, layq = l * (int)a.per_layer_q;
+    int off = cond_prefix(D);                          // end of this layer's conditioners
+    [[maybe_unused]] int offq = cond_prefix_q(D);      // the same in the MFMA-layout weights
     [[maybe_unused]] CondW cw;                         // the NEXT conditioner's recomputation weights, one conditioner ahead
     if constexpr (FAST) {
-      for (int dd = 1; dd < D; ++dd) offq += cond_floats_mfma(dd, 2);
       if (D > 1) {
-        cw = cond_weights(reinterpret_cast<const f4*>(a.wq + l * a.per_layer_q + offq - cond_floats_mfma(D - 1, 2)),
-                          a.prep + hdr_floats(GK) + l * a.per_layer + off - cond_floats(D - 1, 16, 2, GP), D - 1);
+        cw = cond_weights(reinterpret_cast<const f4*>(a.wq + layq + offq - cond_size_q(D - 1)),
+                          a.prep + hdr_floats(GK) + lay + off - cond_size(D - 1), D - 1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     for (int d = D - 1; d >= 1; --d) {
-      off -= cond_floats(d, 16, 2, GP);
+      off -= cond_size(d);
       const int i = first_idx + d * idx_step;
-      float* gw = WGRAD ? gslab + GP + l * a.per_layer + off : nullptr;
+      float* gw = WGRAD ? gslab + GP + lay + off : nullptr;
       WgradPre pre;
       float th[GP], tb[GP];
       if constexpr (FAST) {      // recompute, data backprop and weight gradients on the matrix cores (cnf_backward.h)
-        offq -= cond_floats_mfma(d, 2);
-        const float* wflat = a.prep + hdr_floats(GK) + l * a.per_layer + off;
+        offq -= cond_size_q(d);
+        const float* wflat = a.prep + hdr_floats(GK) + lay + off;
         const CondGeom G{(int)((to_base ? co : cu) - lds) - (int)threadIdx.x + wbase, C_OFF + wbase, ONES_OFF, first_idx,
                          idx_step, GROW, d};
         float h1m[4][4], h2m[4][4];
@@ -199,11 +202,10 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, float* lds, const
                                                   nullptr, true);
         au[i * GROW] += vb;
         // the next conditioner's recomputation weights: covered by this one's backward
-        if (d > 1) cw = cond_weights(reinterpret_cast<const f4*>(a.wq + l * a.per_layer_q + offq - cond_floats_mfma(d - 1, 2)),
-                                     wflat - cond_floats(d - 1, 16, 2, GP), d - 1);
+        if (d > 1) cw = cond_weights(reinterpret_cast<const f4*>(a.wq + layq + offq - cond_size_q(d - 1)), wflat - cond_size(d - 1), d - 1);
         cond_bwd_mfma<WGRAD>(lds, G, (int)((to_base ? Aout : Ain) - lds) + wbase, wflat, Ao, h1m, h2m, tb, gw, stage, pre_o);
       } else {
-        uniform_ptr w = weights + l * a.per_layer + off;
+        uniform_ptr w = weights + lay + off;
         if constexpr (WGRAD) pre = wgrad_prefetch(gw, d);
         float h1[16], h2[16];
         conditioner_keep(w, d, c, to_base ? co : cu, first_idx, idx_step, GROW, h1, h2, th);
@@ -506,6 +508,15 @@ struct VjpArgs {
   int32_t fd2;
   float fd_h, fd_inv_dx;
   const float* gbar;     // [B / fd2, D]
+  // fused score term (cnf_score_fd_vjp): r1 != null.  pts = r3 (the samples at t), r1 / r2 the samples at t -+ dt/2; the
+  // kernel forms the score from ITS forward passes, the residual u = (r2 - r1)/dt + coef score - drift(r3), the per-slice
+  // sums of u^2 (sums), the adjoints of r1 / r2 (rbar1 / rbar2; xbar = the adjoint of r3) and seeds its own backward:
+  // no gbar, and no separate forward launch over the 2 D evaluation points
+  const float* r1; const float* r2;
+  float* rbar1; float* rbar2;
+  double* sums;
+  float inv_dt, coef, drift_a, loss_coef;
+  int32_t drift;         // CnfDrift or -1
 };
 
 // WGRAD=true additionally accumulates the parameter gradient of the pass (the
@@ -549,7 +560,7 @@ __global__ __launch_bounds__(GTS_MAX, 2) void vjp_kernel(const VjpArgs a) {
       }
       const int64_t n_base = a.B / a.fd2;
       c = valid ? a.c[a.c_block >= n_base ? 0 : ib / a.c_block] : 0.0f;
-      ld_bar = valid ? ((k & 1) ? -a.gbar[ib * D + dd] : a.gbar[ib * D + dd]) * a.fd_inv_dx : 0.0f;
+      ld_bar = (valid && a.gbar) ? ((k & 1) ? -a.gbar[ib * D + dd] : a.gbar[ib * D + dd]) * a.fd_inv_dx : 0.0f;
     } else {
       tile_load1(a.pts, St, D, a.div_magic, tile_start, a.B);
       if (a.ybar) tile_load1(a.ybar, Aa, D, a.div_magic, tile_start, a.B);
@@ -558,12 +569,48 @@ __global__ __launch_bounds__(GTS_MAX, 2) void vjp_kernel(const VjpArgs a) {
       ld_bar = (a.ldbar && i < a.B) ? a.ldbar[i] : 0.0f;
     }
     __syncthreads();
-    pass_fwd_stash<FAST, DFIX>(a.m, lds, St, c, a.to_base != 0);
+    const float ldsum = pass_fwd_stash<FAST, DFIX>(a.m, lds, St, c, a.to_base != 0);
+    float ub_drift = 0.0f;      // fused score term: a * u_bar of this lane's (point, dimension) -- the OU drift's share of r3_bar
     if (a.fd2) {       // log_prob = sum -x^2/2 + ildj: the adjoint of the recovered base point is -ld_bar x
       const float* sL = St + L * DT + tid;
+      if (a.r1) {      // the residual of this lane's (point, dimension) from the pair's two log_prob values
+        const bool valid = tid < tp && i < a.B;
+        const int64_t ib = valid ? i / a.fd2 : 0;
+        const int k = (int)(i - ib * a.fd2), dd = k >> 1;
+        const float lp = base_lp(sL, D) + ldsum;
+        const float other = __shfl_xor(lp, 1, 64);             // (groups start at even lanes: the partner is lane ^ 1)
+        const float score = ((k & 1) ? other - lp : lp - other) * a.fd_inv_dx;
+        const int64_t o = ib * D + dd;
+        const float r3d = valid ? a.pts[o] : 0.0f;
+        const float vel = valid ? (a.r2[o] - a.r1[o]) * a.inv_dt : 0.0f;
+        const float drift = a.drift == CNF_DRIFT_OU ? -a.drift_a * r3d : 0.0f;
+        const float u = valid ? fmaf(score, a.coef, vel) - drift : 0.0f;
+        const float ub = 2.0f * a.loss_coef * u;
+        ld_bar = ((k & 1) ? -a.coef : a.coef) * ub * a.fd_inv_dx;
+        ub_drift = a.drift == CNF_DRIFT_OU ? a.drift_a * ub : 0.0f;
+        const bool owner = valid && !(k & 1);                  // one lane of the pair writes / counts
+        if (owner) { a.rbar1[o] = -ub * a.inv_dt; a.rbar2[o] = ub * a.inv_dt; }
+        // per-slice sums of u^2: lanes are ordered by point, so a wave's slices are those of its first and last valid lane
+        const int64_t n_base = a.B / a.fd2;
+        const long long slice = !valid ? -1 : (a.c_block >= n_base ? 0 : (long long)(ib / a.c_block));
+        const int nv = (int)(a.B - tile_start < tp ? a.B - tile_start : tp) - (tid & ~63);      // valid lanes of this wave
+        if (nv > 0) {
+          const long long s_lo = __shfl(slice, 0, 64), s_hi = __shfl(slice, nv < 64 ? nv - 1 : 63, 64);
+          float part = owner ? u * u : 0.0f;
+          if (s_lo == s_hi) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            if ((tid & 63) == 0) unsafeAtomicAdd(a.sums + s_lo, (double)part);
+          } else if (owner) {
+            unsafeAtomicAdd(a.sums + slice, (double)part);
+          }
+        }
+      }
       for (int e = 0; e < D; ++e) Aa[e * GROW + tid] = -ld_bar * sL[e * GROW];
     }
     float* ain = pass_bwd<FAST, WGRAD, DFIX>(a.m, lds, St, Aa, Ab, ld_bar, c, a.to_base != 0, gslab, stage, fa);
+    float* spare = ain == Aa ? Ab : Aa;            // the adjoint buffer the pass finished NOT in: scratch now
+    if (a.fd2 && a.r1) spare[tid] = ub_drift;
     __syncthreads();
     if (a.fd2) {       // xbar[i, e] = sum over the fd2 evaluation points of base point i (fixed order: deterministic)
       if (a.xbar) {
@@ -572,7 +619,7 @@ __global__ __launch_bounds__(GTS_MAX, 2) void vjp_kernel(const VjpArgs a) {
         for (int idx = tid; idx < groups * D; idx += GTS) {
           const int il = idx / D, e = idx - il * D;
           if (first_base + il < n_base) {
-            float sum = 0.0f;
+            float sum = a.r1 ? spare[il * a.fd2 + 2 * e] : 0.0f;      // (+ the OU drift's -J^T u_bar = a u_bar, diagonal)
             for (int k = 0; k < a.fd2; ++k) sum += ain[e * GROW + il * a.fd2 + k];
             a.xbar[(first_base + il) * D + e] = sum;
           }
@@ -1543,6 +1590,7 @@ static int pass_vjp_impl(CnfModel* m, int to_base, const float* pts, const float
   a.slabs = m->grad_slabs; a.n_params = m->n_params;
   a.B = B; a.c_block = c_block; a.to_base = to_base ? 1 : 0; a.div_magic = m->div_magic;
   a.fd2 = 0; a.fd_h = 0.f; a.fd_inv_dx = 0.f; a.gbar = nullptr;
+  a.r1 = a.r2 = nullptr; a.rbar1 = a.rbar2 = nullptr; a.sums = nullptr; a.inv_dt = a.coef = a.drift_a = a.loss_coef = 0.f; a.drift = -1;
   const int D = m->cfg.dim, L = m->cfg.num_layers;
   const int ts = pick_tile([&](int t) { return vjp_lds_bytes(D, L, t, grad != nullptr); });
   const size_t lds = vjp_lds_bytes(D, L, ts, grad != nullptr);
@@ -1586,23 +1634,16 @@ extern "C" int cnf_pass_vjp(CnfModel* m, int to_base, const float* pts, const fl
   return pass_vjp_impl(m, to_base, pts, c, c_block, ybar, ldbar, xbar, grad, params, B, stream);
 }
 
-extern "C" int cnf_logprob_fd_vjp(CnfModel* m, const float* pts, const float* c, int64_t c_block, float dx,
-                                  const float* gbar, float* pts_bar, float* grad, const float* params, int64_t B,
-                                  void* stream_) {
-  if (!m || !pts || !c || !gbar || B < 0 || c_block < 1 || !(dx > 0.f) || (!pts_bar && !grad)) return CNF_ERR_INVALID;
-  if (!grad || !params) return CNF_ERR_INVALID;       // the parameter gradient is what this entry point is for
-  if (!m->params_set) return CNF_ERR_INVALID;
-  if (!cnf_grad_supported(&m->cfg)) return CNF_ERR_UNSUPPORTED;
-  if (B == 0) return CNF_OK;
-  if (!m->grad_slabs) return CNF_ERR_INVALID;          // cnf_grad_enable first
-  hipStream_t stream = (hipStream_t)stream_;
+// The finite-difference launches (cnf_logprob_fd_vjp, cnf_score_fd_vjp): `pts` holds n base points, the kernel
+// differentiates log_prob at their 2 D evaluation points r_i -+ dx/2 e_d (generated in the kernel).
+static int fd_vjp_launch(CnfModel* m, VjpArgs& a, const float* pts, const float* c, int64_t c_block, float dx,
+                         float* pts_bar, float* grad, const float* params, int64_t n, hipStream_t stream) {
   if (wait_for_params(m, stream) != CNF_OK) return CNF_ERR_HIP;
   const int D = m->cfg.dim, L = m->cfg.num_layers;
-  VjpArgs a;
   a.m = model_args(m); a.pts = pts; a.c = c; a.ybar = nullptr; a.ldbar = nullptr; a.xbar = pts_bar;
   a.slabs = m->grad_slabs; a.n_params = m->n_params;
-  a.B = B * 2 * D; a.c_block = c_block; a.to_base = 1; a.div_magic = m->div_magic;
-  a.fd2 = 2 * D; a.fd_h = 0.5f * dx; a.fd_inv_dx = 1.0f / dx; a.gbar = gbar;
+  a.B = n * 2 * D; a.c_block = c_block; a.to_base = 1; a.div_magic = m->div_magic;
+  a.fd2 = 2 * D; a.fd_h = 0.5f * dx; a.fd_inv_dx = 1.0f / dx;
   int ts = pick_tile([&](int t) { return vjp_lds_bytes(D, L, t, true); });
   while (ts < 2 * D && ts < GTS_MAX) ts <<= 1;          // a tile holds at least one group of 2 D evaluation points
   if (ts < 2 * D) return CNF_ERR_UNSUPPORTED;
@@ -1631,6 +1672,42 @@ extern "C" int cnf_logprob_fd_vjp(CnfModel* m, const float* pts, const float* c,
   hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, n_slabs, m->n_params, params,
                      grad, (double)m->sc.span_eff, (double)m->sc.sp_offset);
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+extern "C" int cnf_logprob_fd_vjp(CnfModel* m, const float* pts, const float* c, int64_t c_block, float dx,
+                                  const float* gbar, float* pts_bar, float* grad, const float* params, int64_t B,
+                                  void* stream_) {
+  if (!m || !pts || !c || !gbar || B < 0 || c_block < 1 || !(dx > 0.f) || (!pts_bar && !grad)) return CNF_ERR_INVALID;
+  if (!grad || !params) return CNF_ERR_INVALID;       // the parameter gradient is what this entry point is for
+  if (!m->params_set) return CNF_ERR_INVALID;
+  if (!cnf_grad_supported(&m->cfg)) return CNF_ERR_UNSUPPORTED;
+  if (B == 0) return CNF_OK;
+  if (!m->grad_slabs) return CNF_ERR_INVALID;          // cnf_grad_enable first
+  VjpArgs a;
+  a.gbar = gbar;
+  a.r1 = a.r2 = nullptr; a.rbar1 = a.rbar2 = nullptr; a.sums = nullptr; a.inv_dt = a.coef = a.drift_a = a.loss_coef = 0.f; a.drift = -1;
+  return fd_vjp_launch(m, a, pts, c, c_block, dx, pts_bar, grad, params, B, (hipStream_t)stream_);
+}
+
+extern "C" int cnf_score_fd_vjp(CnfModel* m, const float* r, const float* c, int64_t count, float dt, float dx, float coef,
+                                int32_t drift, float a_, float loss_coef, double* sums, float* rbar, float* grad,
+                                const float* params, int64_t n, void* stream_) {
+  if (!m || !r || !c || !sums || !rbar || !grad || !params || n < 0 || count < 1 || !(dt > 0.f) || !(dx > 0.f))
+    return CNF_ERR_INVALID;
+  if (drift != -1 && drift != CNF_DRIFT_OU) return CNF_ERR_UNSUPPORTED;      // (the coupled 2-D / 3-D fields: cnf_loss_terms_grad)
+  if (!m->params_set) return CNF_ERR_INVALID;
+  if (!cnf_grad_supported(&m->cfg)) return CNF_ERR_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t n_slices = (n + count - 1) / count;
+  if (n_slices > 0 && hipMemsetAsync(sums, 0, sizeof(double) * (size_t)n_slices, stream) != hipSuccess) return CNF_ERR_HIP;
+  if (n == 0) return CNF_OK;
+  if (!m->grad_slabs) return CNF_ERR_INVALID;          // cnf_grad_enable first
+  const int64_t nD = n * m->cfg.dim;
+  VjpArgs a;
+  a.gbar = nullptr;
+  a.r1 = r; a.r2 = r + nD; a.rbar1 = rbar; a.rbar2 = rbar + nD; a.sums = sums;
+  a.inv_dt = 1.0f / dt; a.coef = coef; a.drift_a = a_; a.loss_coef = loss_coef; a.drift = drift;
+  return fd_vjp_launch(m, a, r + 2 * nD, c, count, dx, rbar + 2 * nD, grad, params, n, stream);
 }
 
 extern "C" int cnf_score_residual(const float* r, const float* score, int64_t n, int64_t count, int32_t D, float dt,

@@ -432,6 +432,34 @@ class FlowEngine:
                                                 _stream_ptr(self.device)), "cnf_logprob_fd_vjp")
     return pts_bar
 
+  def score_fd_vjp(self, r, cond, count: int, dt: float, dx: float, coef: float, drift: int, a: float, loss_coef: float,
+                   grad: torch.Tensor):
+    """cnf_score_fd_vjp: per-slice sums (float64 [n / count]) of the score-term residual from r [3n, D] AND its
+    backward in one launch: returns (sums, rbar [3n, D]); the parameter gradient is accumulated into `grad`."""
+    if self._flat is None:
+      raise RuntimeError("load(params) before asking for gradients")
+    if not getattr(self, "_grad_enabled", False):
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
+      self._grad_enabled = True
+    r = self._points(r, "score_fd_vjp")
+    n = r.shape[0] // 3
+    if r.shape[0] != 3 * n or n % count:
+      raise ValueError("r must hold the samples at t - dt/2 | t + dt/2 | t of whole slices")
+    c = self.slice_conds(cond)
+    if c.numel() != n // count:
+      raise ValueError("one condition per slice")
+    self._check_out(grad, (self.cfg.param_count(),), "grad")
+    sums = torch.empty(n // count, dtype=torch.float64, device=self.device)
+    rbar = torch.empty_like(r)
+    if n > 0:
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_score_fd_vjp(self._h, r.data_ptr(), c.data_ptr(), int(count), float(dt), float(dx),
+                                              float(coef), int(drift), float(a), float(loss_coef), sums.data_ptr(),
+                                              rbar.data_ptr(), grad.data_ptr(), self._flat.data_ptr(), n,
+                                              _stream_ptr(self.device)), "cnf_score_fd_vjp")
+    return sums, rbar
+
   def score_residual(self, r, score, count: int, dt: float, coef: float, drift: int, a: float,
                      loss_coef: float = 0.0, want_adjoints: bool = False):
     """cnf_score_residual: per-slice sums (float64 [n / count]) of the score-term residual from r [3n, D]

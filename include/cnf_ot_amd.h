@@ -336,6 +336,22 @@ int cnf_logprob_fd_vjp(CnfModel *m, const float *pts, const float *c,
                        float *pts_bar, float *grad, const float *params,
                        int64_t B, void *stream);
 
+/* The score terms' value AND backward in one launch (value_and_grad of kinetic_with_score_loss_fn /
+ * flow_matching_loss_fn, applications.py:245-374, composed from separate flow launches -- the form
+ * cnf_ot_amd.applications uses from dim 6 up).  r [3n, D] = the samples at t - dt/2 | t + dt/2 | t from one
+ * base -> data launch; per slice of `count` points (condition c[slice])
+ *   sums[s] = sum_{i,d} u_{i,d}^2,  u = (r2 - r1)/dt + coef * score_d(r3) - drift_d(r3),
+ * score by central differences of log_prob as in cnf_logprob_fd, drift = CNF_DRIFT_OU (-a r) or -1 (none).
+ * For d(loss) = loss_coef * d(sum of sums):  rbar [3n, D] receives the adjoints of r (all three blocks, the
+ * r3 block complete: drift, score and the 2 D evaluation points' input adjoints), grad the parameter gradient
+ * (accumulated; needs cnf_grad_enable).  Equals cnf_logprob_fd + cnf_score_residual + cnf_logprob_fd_vjp, but
+ * the 2 D n evaluation points are pushed through the flow ONCE: the kernel that differentiates them forms the
+ * score from its own forward passes (no separate forward launch, no score / sbar tensors). */
+int cnf_score_fd_vjp(CnfModel *m, const float *r, const float *c, int64_t count,
+                     float dt, float dx, float coef, int32_t drift, float a,
+                     float loss_coef, double *sums, float *rbar, float *grad,
+                     const float *params, int64_t n, void *stream);
+
 /* Epilogues of loss terms composed from separate flow launches (what
  * cnf_ot_amd.applications does from dim 6 up, where a rank's few samples cannot
  * fill the GPU from inside one fused kernel).  Model-independent, like

@@ -328,6 +328,48 @@ def test_logprob_fd_score_and_its_backward(dev, D, B):
     assert rel_p <= 1e-4 and rel_x <= 1e-4
 
 
+@pytest.mark.parametrize("D,S,count,drift", [(10, 5, 700, "ou"), (6, 3, 1000, None), (3, 4, 513, "ou"), (2, 2, 2000, None)])
+def test_score_fd_vjp_equals_the_three_launch_form(dev, D, S, count, drift):
+  """cnf_score_fd_vjp (value AND backward of the score terms of applications.py:245-374 in one launch: the kernel
+  that differentiates the 2 D evaluation points forms the score from its own forward passes) against the three
+  launches it replaces -- cnf_logprob_fd + cnf_score_residual + cnf_logprob_fd_vjp -- on the same inputs."""
+  from cnf_ot_amd import FlowConfig, FlowModel, Params, _capi
+  cfg = FlowConfig(dim=D); model = FlowModel(cfg)
+  params = Params.random(cfg, 0.2 if D == 2 else 0.12, seed=80 + D, device=dev)
+  eng = model.terms_backend(params)
+  eng.set_pwl(0)
+  n = S * count
+  dt, dx, coef, a, loss_coef = 0.01, 0.01, 0.5, 1.3, 0.7 / n
+  dr = -1 if drift is None else _capi.DRIFTS[drift]
+  t = torch.linspace(0.1, 0.9, S, device=dev)
+  z = eng.normal(11, n)
+  half = 0.5 * dt
+  c3 = torch.cat([t - half, t + half, t])
+  r, _ = eng.forward_logdet(z.repeat(3, 1), c3.repeat_interleave(count), want_logdet=False)
+  r = r.contiguous()
+  # the three-launch form
+  g_ref = torch.zeros_like(params.flat)
+  r3 = r[2 * n:]
+  score = eng.logprob_fd(r3, t, dx)
+  sums_ref, rbar_ref, sbar = eng.score_residual(r, score, count, dt, coef, dr, a, loss_coef, True)
+  r3bar = eng.logprob_fd_vjp(r3, t, dx, sbar, g_ref)
+  rbar_ref[2 * n:] += r3bar
+  # one launch
+  g = torch.zeros_like(params.flat)
+  sums, rbar = eng.score_fd_vjp(r, t, count, dt, dx, coef, dr, a, loss_coef, g)
+  torch.cuda.synchronize()
+  rel = lambda x, y: (x - y).abs().max().item() / max(y.abs().max().item(), 1e-30)
+  e_s, e_r, e_g = rel(sums, sums_ref), rel(rbar, rbar_ref), rel(g, g_ref)
+  print(f"\n[score_fd_vjp D={D} drift={drift}] sums rel {e_s:.2e}  rbar rel {e_r:.2e}  grad rel {e_g:.2e}")
+  # (the score is a difference of two log_prob values over dx = 0.01: the two forms evaluate the conditioner with
+  # different instruction sequences -- packed vector ALU vs matrix cores -- and the difference's rounding is amplified 100 x)
+  assert e_s <= 2e-4 and e_r <= 2e-3 and e_g <= 2e-3
+  # the same call again: accumulates, bitwise reproducible
+  g2 = torch.zeros_like(params.flat)
+  sums2, rbar2 = eng.score_fd_vjp(r, t, count, dt, dx, coef, dr, a, loss_coef, g2)
+  assert torch.equal(g, g2) and torch.equal(rbar, rbar2)
+
+
 @pytest.mark.parametrize("L,S,Bs", [(2, 5, 6002), (3, 70, 1500)])
 @pytest.mark.parametrize("to_base", [False, True])
 def test_pass_vjp_table_form_matches_mlp_backward(dev, to_base, L, S, Bs):
