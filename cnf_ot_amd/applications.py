@@ -71,6 +71,7 @@ class _Ctx:
     self.shard = shard if shard is not None else current_shard()
     self.grad = grad
     self._noise = {}
+    self._passes = []       # base -> data backward passes waiting for ONE launch (defer_pass_vjp)
 
   def noise(self, n_global: int) -> torch.Tensor:
     """This rank's rows of the first n_global samples of the seed's stream."""
@@ -86,8 +87,36 @@ class _Ctx:
       return self.be.loss_terms_grad(spec, pts, t, B_local, shared, coef, self.grad)
     return self.be.loss_terms(spec, pts, t, B_local, shared)
 
+  def defer_pass_vjp(self, z, conds, count: int, ybar, ldbar):
+    """Queue the backward of a base -> data pass (points z [S * count, D], one condition per slice of `count`
+    points) instead of launching it: the passes of a loss's terms go out as ONE cnf_pass_vjp launch in `reduce`.
+    A rank's share of a term is often too small to fill the GPU on its own (config 4: 512 and 1 536 waves for 2 048
+    wave slots, each wave one tile -- two launches took two tile times, the merged one takes one)."""
+    self._passes.append((z, np.asarray(conds, dtype=np.float32).reshape(-1), int(count), ybar, ldbar))
+
+  def flush_passes(self):
+    passes, self._passes = self._passes, []
+    if not passes:
+      return
+    be = self.be
+    if len(passes) == 1:
+      z, conds, count, ybar, ldbar = passes[0]
+      be.pass_vjp(z, be.slice_conds(conds), ybar, ldbar, False, grad=self.grad, want_xbar=False)
+      return
+    g = 0
+    for _, _, count, _, _ in passes:
+      g = int(np.gcd(g, count))
+    conds = np.concatenate([np.repeat(c, count // g) for _, c, count, _, _ in passes])
+    z = torch.cat([p[0] for p in passes])
+    ybar = torch.cat([p[3] if p[3] is not None else torch.zeros_like(p[0]) for p in passes])
+    ldbar = None
+    if any(p[4] is not None for p in passes):
+      ldbar = torch.cat([p[4] if p[4] is not None else torch.zeros(p[0].shape[0], device=z.device) for p in passes])
+    be.pass_vjp(z, be.slice_conds(conds), ybar, ldbar, False, grad=self.grad, want_xbar=False)
+
   def reduce(self, sums: Sequence[torch.Tensor]) -> torch.Tensor:
     """The ONE collective of a loss evaluation: partial sums (+ the gradient)."""
+    self.flush_passes()
     parts = [s.reshape(-1).to(torch.float64) for s in sums]
     n = sum(p.numel() for p in parts)
     if self.grad is not None and self.shard.world > 1:
@@ -266,7 +295,7 @@ def _score_terms_unfused(ctx, conds, batch_size, dt, dx, coef_score, loss_coef, 
     # value AND backward of the score term in one launch: the kernel that differentiates the 2 D evaluation points
     # forms the score from its own forward passes (no separate forward launch over them)
     sums, rbar = be.score_fd_vjp(r, tt, count, dt, dx, coef_score, drift, a, loss_coef, ctx.grad)
-    be.pass_vjp(z3, c3, rbar, None, False, grad=ctx.grad, want_xbar=False)
+    ctx.defer_pass_vjp(z3, np.concatenate([th - half, th + half, th]), count, rbar, None)
     return sums
   r3 = r[2 * n:]
   score = be.logprob_fd(r3, tt, dx)
@@ -274,7 +303,7 @@ def _score_terms_unfused(ctx, conds, batch_size, dt, dx, coef_score, loss_coef, 
   if want:
     r3bar = be.logprob_fd_vjp(r3, tt, dx, sbar, ctx.grad)     # adjoint of r3 through the score; + parameter gradient
     rbar[2 * n:] += r3bar
-    be.pass_vjp(z3, c3, rbar, None, False, grad=ctx.grad, want_xbar=False)
+    ctx.defer_pass_vjp(z3, np.concatenate([th - half, th + half, th]), count, rbar, None)
   return sums
 
 
@@ -288,7 +317,10 @@ def _reverse_kl_unfused(ctx, T, beta, cond, batch_size, coef):
   want = ctx.grad is not None
   total, ybar, lpbar = be.rkl_residual(y, lp, cond, T, beta, coef, want)
   if want:      # lp = base(noise) - fldj: the adjoint of the pass's log-det output is -lpbar
-    be.pass_vjp(z, c, ybar, -lpbar, False, grad=ctx.grad, want_xbar=False)
+    if _use_table_backward(ctx, z.shape[1], count, 1):      # (dim 2, large batch: the table form, on its own)
+      be.pass_vjp(z, c, ybar, -lpbar, False, grad=ctx.grad, want_xbar=False)
+    else:
+      ctx.defer_pass_vjp(z, [cond], count, ybar, -lpbar)
   return total
 
 
