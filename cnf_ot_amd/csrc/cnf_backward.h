@@ -408,15 +408,17 @@ __device__ __forceinline__ int cond_row_off(const CondGeom& G, int k) {
 // conditioner AHEAD of their use -- a dependent L2 round trip costs a lone wave 1-2 us, as long as the conditioner's
 // arithmetic.  a0[t]: W0pad[4t + g][i] (0 beyond row d + 1); A1 / A2, bias1 / bias2: the 16 x 16 layers (prepare_kernel's `wq`).
 // (the output layer's A2 / bias2 are fetched at the start of the evaluation itself: the first two layers cover them)
-struct CondW { float a0[4]; f4 A1, bias1; const f4* p2; };
+struct CondW { float a0[4]; f4 A1, bias1; int q2; };      // q2: (wave-uniform) offset of the output layer's operands in `wq`, in f4 units
 
-__device__ __forceinline__ CondW cond_weights(const f4* __restrict__ wq, const float* __restrict__ wflat, int d) {
+// wq_layer: the flow layer's MFMA-layout weights, q_off: this conditioner's offset in them (floats)
+__device__ __forceinline__ CondW cond_weights(const float* __restrict__ wq_layer, int q_off, const float* __restrict__ wflat, int d) {
   const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
-  const f4* p = wq + (2 + d) * 64;
+  const int q1 = (q_off >> 2) + (2 + d) * 64;
+  const f4* p = reinterpret_cast<const f4*>(wq_layer) + q1;
   CondW w;
 #pragma unroll
   for (int t = 0; t < 4; ++t) w.a0[t] = 4 * t + g <= d + 1 ? wflat[(4 * t + g) * 16 + s] : 0.0f;
-  w.A1 = p[lane]; w.bias1 = p[64 + lane]; w.p2 = p + 128 + lane;
+  w.A1 = p[lane]; w.bias1 = p[64 + lane]; w.q2 = q1 + 128;
   return w;
 }
 
@@ -434,11 +436,12 @@ constexpr int STAGE_FLOATS = 16 * STG;           // per wave: ONE [unit][sample]
 
 // Conditioner forward (M = 2) on the matrix cores: theta in the lane layout; both hidden activations are handed back
 // in MFMA layout (the backward's ReLU masks are their signs, and they are the operands of its weight-gradient GEMMs).
-__device__ __forceinline__ void cond_fwd_mfma(const float* lds, const CondGeom& G, const CondW& w, float (&h1m)[4][4],
-                                              float (&h2m)[4][4], float (&th)[16]) {
+__device__ __forceinline__ void cond_fwd_mfma(const float* lds, const CondGeom& G, const float* __restrict__ wq_layer, const CondW& w,
+                                              float (&h1m)[4][4], float (&h2m)[4][4], float (&th)[16]) {
   const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
   const int nst = (G.d + 5) >> 2;                  // k-steps of the first layer: ceil((d + 2) / 4)
-  const f4 A2 = w.p2[0], bias2 = w.p2[64];
+  const f4* p2 = reinterpret_cast<const f4*>(wq_layer) + w.q2 + lane;
+  const f4 A2 = p2[0], bias2 = p2[64];
   __builtin_amdgcn_sched_barrier(0);
   f4 acc[4];
 #pragma unroll

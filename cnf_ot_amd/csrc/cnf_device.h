@@ -1203,6 +1203,12 @@ __host__ __device__ inline int64_t cond_floats_p(int d, int H, int M, int P, boo
 struct SliceSum {
   double run = 0.0;
   int64_t slice = -1;
+  // (both are wave-uniform: kept in scalar registers -- four vector registers the backward kernels have no room for)
+  static __device__ __forceinline__ double uniform(double x) {
+    const long long b = __double_as_longlong(x);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+  }
   __device__ __forceinline__ void flush(double* sums) {
     if (slice >= 0 && (threadIdx.x & 63) == 0 && run != 0.0) unsafeAtomicAdd(sums + slice, run);
     run = 0.0;
@@ -1210,7 +1216,7 @@ struct SliceSum {
   // s: the tile's slice (wave-uniform); part: the tile's sum over the wave's lanes (the same in every lane)
   __device__ __forceinline__ void add(double* sums, int64_t s, float part) {
     if (s != slice) { flush(sums); slice = s; }
-    run += (double)part;
+    run = uniform(run + (double)part);
   }
 };
 

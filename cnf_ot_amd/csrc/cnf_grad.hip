@@ -107,8 +107,9 @@ __device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, float* lds, 
     uniform_ptr w = weights + l * (int)a.per_layer;
     [[maybe_unused]] const float* wflat = a.prep + hdr_floats(GK) + l * (int)a.per_layer;
     [[maybe_unused]] const float* wq = a.wq + l * (int)a.per_layer_q;
+    [[maybe_unused]] int qo = 0;       // this conditioner's offset in the layer's MFMA-layout weights
     [[maybe_unused]] CondW cw;         // the NEXT conditioner's weights: one conditioner ahead (cnf_backward.h)
-    if constexpr (FAST) { if (D > 1) cw = cond_weights(reinterpret_cast<const f4*>(wq), wflat, 1); __builtin_amdgcn_sched_barrier(0); }
+    if constexpr (FAST) { if (D > 1) cw = cond_weights(wq, 0, wflat, 1); __builtin_amdgcn_sched_barrier(0); }
     float o, ld;
     if (to_base) table_spline<GK, false, FAST, float>(tab, cu[first_idx * GROW], a.sc, o, ld);
     else table_spline<GK, true, FAST, float>(tab, cu[first_idx * GROW], a.sc, o, ld);
@@ -121,12 +122,12 @@ __device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, float* lds, 
         const CondGeom G{(int)((to_base ? co : cu) - lds) - (int)threadIdx.x + wbase, C_OFF + wbase, ONES_OFF, first_idx,
                          idx_step, GROW, d};
         const CondW cur = cw;
-        wq += cond_size_q(d);
+        qo += cond_size_q(d);
         wflat += cond_size(d);
-        if (d + 1 < D) cw = cond_weights(reinterpret_cast<const f4*>(wq), wflat, d + 1);
+        if (d + 1 < D) cw = cond_weights(wq, qo, wflat, d + 1);
         __builtin_amdgcn_sched_barrier(0);
         float h1m[4][4], h2m[4][4];
-        cond_fwd_mfma(lds, G, cur, h1m, h2m, th);
+        cond_fwd_mfma(lds, G, wq, cur, h1m, h2m, th);
       } else {
         conditioner<16, GP, float>(w, d, 2, c, to_base ? co : cu, first_idx, idx_step, GROW, th);
         w += cond_size(d);
@@ -143,10 +144,14 @@ __device__ __forceinline__ float pass_fwd_stash(const ModelArgs& a, float* lds, 
 // backward of the pass whose stash is in St.  Aa holds the adjoint of the final
 // output on entry; the function ping-pongs between Aa and Ab and returns the
 // buffer that holds the adjoint of the pass input.
-template <bool FAST, bool WGRAD = true, int DFIX = 0>
+// fa_lds (optional): the `first` spline's per-bin adjoint sums live in 16 LDS rows instead of `fa` -- sixteen registers
+// that are then free during the conditioner loop (the generic-dimension loss kernel has none to spare)
+// AHEAD: the recomputation weights of the next conditioner are fetched during the current one's backward (twelve
+// registers held across it; the generic-dimension loss kernel, whose tile state is larger, fetches them at use)
+template <bool FAST, bool WGRAD = true, int DFIX = 0, bool AHEAD = true>
 __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, float* lds, const float* St, float* Aa,
                                            float* Ab, float ld_bar, float c, bool to_base, float* gslab,
-                                           float* stage, FirstAcc& fa) {
+                                           float* stage, FirstAcc& fa, float* fa_lds = nullptr) {
   const int D = DFIX ? DFIX : a.D;
   const float* tab = lds;
   const int wbase = threadIdx.x & ~63;
@@ -167,10 +172,9 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, float* lds, const
     int off = cond_prefix(D);                          // end of this layer's conditioners
     [[maybe_unused]] int offq = cond_prefix_q(D);      // the same in the MFMA-layout weights
     [[maybe_unused]] CondW cw;                         // the NEXT conditioner's recomputation weights, one conditioner ahead
-    if constexpr (FAST) {
+    if constexpr (FAST && AHEAD) {
       if (D > 1) {
-        cw = cond_weights(reinterpret_cast<const f4*>(a.wq + layq + offq - cond_size_q(D - 1)),
-                          a.prep + hdr_floats(GK) + lay + off - cond_size(D - 1), D - 1);
+        cw = cond_weights(a.wq + layq, offq - cond_size_q(D - 1), a.prep + hdr_floats(GK) + lay + off - cond_size(D - 1), D - 1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -186,7 +190,8 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, float* lds, const
         const CondGeom G{(int)((to_base ? co : cu) - lds) - (int)threadIdx.x + wbase, C_OFF + wbase, ONES_OFF, first_idx,
                          idx_step, GROW, d};
         float h1m[4][4], h2m[4][4];
-        cond_fwd_mfma(lds, G, cw, h1m, h2m, th);
+        if constexpr (!AHEAD) cw = cond_weights(a.wq + layq, offq, wflat, d);
+        cond_fwd_mfma(lds, G, a.wq + layq, cw, h1m, h2m, th);
         // fetched here, the spline backward ahead of their first use: the first data-backprop operand and the first
         // accumulator tile of the weight gradient (the others at the start of cond_bwd_mfma)
         const int o_wo = (1 + d) * 16 + 16 + 256 + 16;
@@ -202,7 +207,7 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, float* lds, const
                                                   nullptr, true);
         au[i * GROW] += vb;
         // the next conditioner's recomputation weights: covered by this one's backward
-        if (d > 1) cw = cond_weights(reinterpret_cast<const f4*>(a.wq + layq + offq - cond_size_q(d - 1)), wflat - cond_size(d - 1), d - 1);
+        if constexpr (AHEAD) { if (d > 1) cw = cond_weights(a.wq + layq, offq - cond_size_q(d - 1), wflat - cond_size(d - 1), d - 1); }
         cond_bwd_mfma<WGRAD>(lds, G, (int)((to_base ? Aout : Ain) - lds) + wbase, wflat, Ao, h1m, h2m, tb, gw, stage, pre_o);
       } else {
         uniform_ptr w = weights + lay + off;
@@ -219,10 +224,28 @@ __device__ __forceinline__ float* pass_bwd(const ModelArgs& a, float* lds, const
       }
     }
     float vb0;
-    if (to_base) vb0 = table_spline_bwd<GK, false, FAST>(tab, cu[first_idx * GROW], co[first_idx * GROW], ao[first_idx * GROW],
-                                                         ld_bar, a.sc, fa.Wb, fa.Hb, fa.Db);
-    else vb0 = table_spline_bwd<GK, true, FAST>(tab, cu[first_idx * GROW], co[first_idx * GROW], ao[first_idx * GROW],
-                                                ld_bar, a.sc, fa.Wb, fa.Hb, fa.Db);
+    if (fa_lds) {
+      FirstAcc t0;
+#pragma unroll
+      for (int j = 0; j < GK; ++j) { t0.Wb[j] = 0.0f; t0.Hb[j] = 0.0f; }
+#pragma unroll
+      for (int j = 0; j <= GK; ++j) t0.Db[j] = 0.0f;
+      if (to_base) vb0 = table_spline_bwd<GK, false, FAST>(tab, cu[first_idx * GROW], co[first_idx * GROW], ao[first_idx * GROW],
+                                                           ld_bar, a.sc, t0.Wb, t0.Hb, t0.Db);
+      else vb0 = table_spline_bwd<GK, true, FAST>(tab, cu[first_idx * GROW], co[first_idx * GROW], ao[first_idx * GROW],
+                                                  ld_bar, a.sc, t0.Wb, t0.Hb, t0.Db);
+      float* f = fa_lds + threadIdx.x;
+#pragma unroll
+      for (int j = 0; j < GK; ++j) { f[j * GROW] += t0.Wb[j]; f[(GK + j) * GROW] += t0.Hb[j]; }
+#pragma unroll
+      for (int j = 0; j <= GK; ++j) f[(2 * GK + j) * GROW] += t0.Db[j];
+    } else if (to_base) {
+      vb0 = table_spline_bwd<GK, false, FAST>(tab, cu[first_idx * GROW], co[first_idx * GROW], ao[first_idx * GROW],
+                                              ld_bar, a.sc, fa.Wb, fa.Hb, fa.Db);
+    } else {
+      vb0 = table_spline_bwd<GK, true, FAST>(tab, cu[first_idx * GROW], co[first_idx * GROW], ao[first_idx * GROW],
+                                             ld_bar, a.sc, fa.Wb, fa.Hb, fa.Db);
+    }
     au[first_idx * GROW] += vb0;
     float* t = Aout; Aout = Ain; Ain = t;
   }
@@ -291,11 +314,15 @@ __global__ __launch_bounds__(GTS_MAX, 2) void grad_kernel(const GradArgs a) {
   float* R3b = R3 + DT;
   float* Ub = R3b + DT;
   float* stage = Ub + DT + (threadIdx.x >> 6) * STAGE_FLOATS;
+  // generic dimension: the `first` spline's 16 accumulators per lane in LDS (pass_bwd), not in registers
+  float* fa_lds = DFIX ? nullptr : Ub + DT + (GTS >> 6) * STAGE_FLOATS;
   for (int i = threadIdx.x; i < HDR; i += GTS) lds[i] = a.m.prep[i];
   tile_consts(lds);
+  if (!DFIX) { for (int j = 0; j < GP; ++j) fa_lds[j * GROW + threadIdx.x] = 0.0f; }
   const int tid = threadIdx.x;
   const int kind = a.spec.kind;
-  float* gslab = a.slabs + ((int64_t)blockIdx.x * (GTS >> 6) + (tid >> 6)) * a.n_params;
+  // (wave-uniform: a scalar register pair, not two vector registers)
+  float* gslab = a.slabs + (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (GTS >> 6) + (tid >> 6))) * a.n_params;
   slab_clear(gslab, a.n_params, tid & 63);
   FirstAcc fa;
 #pragma unroll
@@ -455,7 +482,7 @@ __global__ __launch_bounds__(GTS_MAX, 2) void grad_kernel(const GradArgs a) {
           break;
       }
       if (do_bwd) {
-        const float* ain = pass_bwd<FAST, true, DFIX>(a.m, lds, St, Aa, Ab, ld_bar, c, to_base, gslab, stage, fa) + tid;
+        const float* ain = pass_bwd<FAST, true, DFIX, DFIX != 0>(a.m, lds, St, Aa, Ab, ld_bar, c, to_base, gslab, stage, fa, fa_lds) + tid;
         if (role == R_LPM || role == R_LPPB)
           for (int e = 0; e < D; ++e) r3b[e * GROW] += ain[e * GROW];
       }
@@ -468,10 +495,15 @@ __global__ __launch_bounds__(GTS_MAX, 2) void grad_kernel(const GradArgs a) {
   ssum.flush(a.sums);
   // per-bin adjoint sums of the shared `first` spline: wave reduce, one owner write
   float red[GP];
+  if (!DFIX) {
 #pragma unroll
-  for (int j = 0; j < GK; ++j) { red[j] = fa.Wb[j]; red[GK + j] = fa.Hb[j]; }
+    for (int j = 0; j < GP; ++j) red[j] = fa_lds[j * GROW + tid];
+  } else {
 #pragma unroll
-  for (int j = 0; j <= GK; ++j) red[2 * GK + j] = fa.Db[j];
+    for (int j = 0; j < GK; ++j) { red[j] = fa.Wb[j]; red[GK + j] = fa.Hb[j]; }
+#pragma unroll
+    for (int j = 0; j <= GK; ++j) red[2 * GK + j] = fa.Db[j];
+  }
 #pragma unroll
   for (int j = 0; j < GP; ++j) {
 #pragma unroll
@@ -530,7 +562,7 @@ __global__ __launch_bounds__(GTS_MAX, 2) void vjp_kernel(const VjpArgs a) {
   float* Aa = St + (L + 1) * DT;
   float* Ab = Aa + DT;
   float* stage = Ab + DT + (threadIdx.x >> 6) * STAGE_FLOATS;       // (WGRAD = false: nothing is staged)
-  float* gslab = WGRAD ? a.slabs + ((int64_t)blockIdx.x * (GTS >> 6) + (threadIdx.x >> 6)) * a.n_params : nullptr;
+  float* gslab = WGRAD ? a.slabs + (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (GTS >> 6) + (threadIdx.x >> 6))) * a.n_params : nullptr;
   if (WGRAD) slab_clear(gslab, a.n_params, threadIdx.x & 63);
   for (int i = threadIdx.x; i < HDR; i += GTS) lds[i] = a.m.prep[i];
   tile_consts(lds);
@@ -1390,10 +1422,11 @@ __global__ __launch_bounds__(256) void rkl_residual_kernel(const RklArgs a) {
 using namespace cnf;
 
 #undef GTS
-static size_t grad_lds_bytes(int D, int L, int ts = GTS_MAX) {
+static size_t grad_lds_bytes(int D, int L, int ts = GTS_MAX, bool generic = true) {
   // table, ones / zeros, condition column + noise + (L+1) stashes + 2 adjoint buffers + velocity, r3, r3_bar, u_bar
   // (rows of ts + 4 floats) + one MFMA staging area per wave
-  return (size_t)(hdr_floats(GK) + 64 + (ts + 4) + D * (ts + 4) * (1 + (L + 1) + 6) + (ts / 64) * STAGE_FLOATS) * sizeof(float);
+  return (size_t)(hdr_floats(GK) + 64 + (ts + 4) + D * (ts + 4) * (1 + (L + 1) + 6) + (ts / 64) * STAGE_FLOATS +
+                  (generic ? GP * (ts + 4) : 0)) * sizeof(float);     // (generic-dimension kernel: + rows for the `first` spline's accumulators)
 }
 static size_t vjp_lds_bytes(int D, int L, int ts, bool wgrad) {
   // (without weight gradients nothing is staged)
@@ -1446,8 +1479,9 @@ extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const f
   a.slabs = m->grad_slabs; a.n_params = m->n_params;
   a.B = B; a.n_slices = n_slices; a.pts_slice_stride = pts_shared ? 0 : B;
   a.scale = scale; a.div_magic = m->div_magic;
-  const int ts = pick_tile([&](int t) { return grad_lds_bytes(D, L, t); });
-  const size_t lds = grad_lds_bytes(D, L, ts);
+  const bool generic = !(m->fast_math && D == 2);          // (grad_kernel<true, 2> keeps everything in registers)
+  const int ts = pick_tile([&](int t) { return grad_lds_bytes(D, L, t, generic); });
+  const size_t lds = grad_lds_bytes(D, L, ts, generic);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
   const int64_t n_tiles = ((B + ts - 1) / ts) * n_slices;
   const int64_t max_grid = m->grad_max_blocks * 4 / (ts / 64);           // (slabs: one per wave)

@@ -48,8 +48,9 @@ def main(tag):
     gui = g("GRBM_GUI_ACTIVE")
     mops = g("SQ_INSTS_VALU_MFMA_MOPS_F32")
     if gui and mfma_busy is not None:
-      # SQ_VALU_MFMA_BUSY_CYCLES sums over the SIMDs the counter sees; normalised by kernel cycles x SIMDs
-      d["mfma_busy_pct_of_kernel_cycles_all_simds"] = 100.0 * mfma_busy / (gui * SIMDS)
+      # SQ_VALU_MFMA_BUSY_CYCLES: cycles (32 per v_mfma_f32_16x16x4_f32) summed over every SIMD of the chip;
+      # GRBM_GUI_ACTIVE: the kernel's cycles summed over the 8 XCDs (MI355X_MICROARCH.md)
+      d["mfma_busy_pct_of_simd_cycles"] = 100.0 * mfma_busy / (gui / 8.0 * SIMDS)
     if mops is not None and kern in dur and dur[kern]["avg_ns"] > 0:
       d["mfma_flop_per_launch (MOPS x 512)"] = mops * 512
       d["mfma_tflops"] = mops * 512 / dur[kern]["avg_ns"] / 1e3
