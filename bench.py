@@ -186,7 +186,14 @@ def per_call_section(eng, model, params, noise1, t_slices, y1, lp1, dev):
                                                        sample_shape=(BATCH,)))
   out["model_apply_eager"] = {"ms_per_call": dt * 1e3, "value": BATCH / dt, "kernel": eng.last_path(),
                               "note": "model.apply.sample_and_log_prob(params, cond=[B,1]) -- the reference's literal "
-                                      "form (applications.py:153-158), outputs allocated per call"}
+                                      "form (applications.py:153-158), outputs allocated per call, parameters "
+                                      "prepared on every call (cnf_model_set_params: pure-function semantics)"}
+  model.assume_unchanged_params = True       # opt-in: skip the preparation while torch sees no write to `params`
+  dt = loop(lambda i: model.apply.sample_and_log_prob(params, cond=cond_b1[i % len(cond_b1)], noise=noise1,
+                                                       sample_shape=(BATCH,)))
+  model.assume_unchanged_params = False
+  out["model_apply_eager_assume_unchanged"] = {"ms_per_call": dt * 1e3, "value": BATCH / dt,
+                                               "note": "the same with FlowModel(assume_unchanged_params=True)"}
   try:       # the same launch-bound loop captured once into a HIP graph and replayed (entry points only enqueue)
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))

@@ -109,6 +109,29 @@ __device__ __forceinline__ BinPartials rqs_partials(float x, float x0, float bw,
   return rqs_partials_at<FAST>(z, 1.0f - z, x, bw, bh, d0, d1, lo, hi);
 }
 
+// Partials of the INVERSE map at the point it maps v to, formed here from the bin's own quantities (not taken from a
+// forward pass, whose output can lie a rounding outside this bin next to a knot).  The quadratic is solved from the
+// nearer end of the bin (the spline is symmetric under z <-> 1 - z, d0 <-> d1, dy <-> bh - dy), so the SMALL one of
+// z and 1 - z comes out to full relative precision: where the inverse saturates against a knot, 1 - z recovered from a
+// float32 output is good to a few per cent only, and the log-det partials divide by it (scripts/debug_xbar_tail.py).
+template <bool FAST = false>
+__device__ __forceinline__ BinPartials rqs_partials_inv(float v, float x0, float y0, float bw, float bh, float d0,
+                                                        float d1, float lo, float hi) {
+  using M = Math<FAST>;
+  const float sl = bh * M::rcp(bw), st = d0 + d1 - 2.0f * sl;
+  const float dy = fminf(fmaxf(v - y0, 0.0f), bh), dyt = bh - dy;
+  const bool low = dy <= dyt;
+  const float t = low ? dy : dyt, da = low ? d0 : d1;
+  const float c = -sl * t, b = fmaf(-st, t, da * bh), a2 = fmaf(sl, bh, -b);
+  const float disc = fmaf(b, b, a2 * c * -4.0f);
+  const float r = clip01(M::div(c * -2.0f, b + M::sqrt(disc)));
+  const float z = low ? r : 1.0f - r, omz = low ? 1.0f - r : r;
+  float out = low ? fmaf(bw, r, x0) : fmaf(-bw, r, x0 + bw);
+  if (v <= lo) out = fmaf(v - lo, M::rcp(d0), lo);      // rqs_bin_eval's linear tails
+  if (v >= hi) out = fmaf(v - hi, M::rcp(d1), hi);
+  return rqs_partials_at<FAST>(z, omz, out, bw, bh, d0, d1, lo, hi);
+}
+
 // ---------------------------------------------------------------------------
 // Backward of the spline of the shared `first` parameters.  The table holds
 // the normalised knots; the softmax / softplus Jacobians are linear in the
@@ -122,9 +145,12 @@ __device__ __forceinline__ float table_spline_bwd(const float* tab, float v, flo
                                                   float (&Db)[K + 1]) {
   const float* pos = tab + tab_off(INV ? F_YK : F_XK, K);
   const int k = bin_of<K>(pos, v);
-  const float x = INV ? out : v;
-  const BinPartials p = rqs_partials<FAST>(x, gather<K>(tab, F_X0, k), gather<K>(tab, F_BW, k), gather<K>(tab, F_BH, k),
-                                           gather<K>(tab, F_D0, k), gather<K>(tab, F_D1, k), sc.lo, sc.hi);
+  (void)out;      // (INV: the output is formed here, on this bin's knots, like cond_spline_bwd's: ADVICE r2)
+  const float x0 = gather<K>(tab, F_X0, k), bw = gather<K>(tab, F_BW, k), bh = gather<K>(tab, F_BH, k);
+  const float d0 = gather<K>(tab, F_D0, k), d1 = gather<K>(tab, F_D1, k);
+  BinPartials p;
+  if constexpr (INV) p = rqs_partials_inv<FAST>(v, x0, gather<K>(tab, F_Y0, k), bw, bh, d0, d1, sc.lo, sc.hi);
+  else p = rqs_partials<FAST>(v, x0, bw, bh, d0, d1, sc.lo, sc.hi);
   const BinAdjoint a = bin_adjoint<INV, FAST>(p, o_bar, l_bar);
 #pragma unroll
   for (int j = 0; j < K; ++j) {
@@ -186,23 +212,8 @@ __device__ __forceinline__ float cond_spline_bwd(const float (&th)[3 * K + 1], f
   }
   const float d0 = knot_slope<FAST, float>(t0, sc), d1 = knot_slope<FAST, float>(t1, sc);
   BinPartials p;
-  if (INV && form_out) {      // rqs_bin_eval's inverse branch and cond_spline's linear tails
-    // The quadratic is solved from the nearer end of the bin (the spline is symmetric under z <-> 1 - z, d0 <-> d1,
-    // dy <-> bh - dy), so the SMALL one of z and 1 - z comes out to full relative precision: where the inverse
-    // saturates against a knot, 1 - z recovered from the float32 output is good to a few per cent only, and the
-    // log-det partials divide by it (scripts/debug_xbar_tail.py)
-    const float sl = bh * M::rcp(bw), st = d0 + d1 - 2.0f * sl;
-    const float dy = fminf(fmaxf(v - y0, 0.0f), bh), dyt = bh - dy;
-    const bool low = dy <= dyt;
-    const float t = low ? dy : dyt, da = low ? d0 : d1;
-    const float c = -sl * t, b = fmaf(-st, t, da * bh), a2 = fmaf(sl, bh, -b);
-    const float disc = fmaf(b, b, a2 * c * -4.0f);
-    const float r = clip01(M::div(c * -2.0f, b + M::sqrt(disc)));
-    const float z = low ? r : 1.0f - r, omz = low ? 1.0f - r : r;
-    out = low ? fmaf(bw, r, x0) : fmaf(-bw, r, x0 + bw);
-    if (v <= sc.lo) out = fmaf(v - sc.lo, M::rcp(d0), sc.lo);
-    if (v >= sc.hi) out = fmaf(v - sc.hi, M::rcp(d1), sc.hi);
-    p = rqs_partials_at<FAST>(z, omz, out, bw, bh, d0, d1, sc.lo, sc.hi);
+  if (INV && form_out) {
+    p = rqs_partials_inv<FAST>(v, x0, y0, bw, bh, d0, d1, sc.lo, sc.hi);
   } else {
     p = rqs_partials<FAST>(INV ? out : v, x0, bw, bh, d0, d1, sc.lo, sc.hi);
   }

@@ -88,7 +88,8 @@ struct CnfModel {
   // Allocated ONLY by cnf_model_reserve; the compute entry points look theirs up and never allocate.
   // cnf_grad_enable: per-piece gradient statistics of the table backward (cnf_grad.hip), PWL_STAT_SLICES slices
   float* pwl_stats;
-  struct PwlWorkspace { float* tables; int64_t sets; uint32_t epoch; };
+  // retired: blocks of this stream outgrown by a later reservation, kept alive for graphs captured on them
+  struct PwlWorkspace { float* tables; int64_t sets; uint32_t epoch; std::vector<float*> retired; };
   std::mutex pwl_mu;
   std::unordered_map<void*, PwlWorkspace> pwl_ws;
   // cnf_model_set_params records `prep_event` after its kernel; a compute call on another stream waits for it

@@ -85,64 +85,84 @@ __global__ void prepare_kernel(const float* __restrict__ params, float* __restri
                                int64_t per_layer_q, int64_t mfma_off, int64_t tabd_off, int H, int periodic) {
   const int P = 3 * K + 1;
   const int hdr = hdr_floats(K);
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_params - P;
-       i += (int64_t)gridDim.x * blockDim.x)
-    prep[hdr + i] = params[P + i];
-  if (mfma_off > 0) {
-    // MFMA-layout copy of every conditioner (H = P = 16): see conditioner_mfma.
-    const int nc = L * (D - 1);
-    for (int ci = blockIdx.x; ci < nc; ci += gridDim.x) {
-      const int l = ci / (D - 1), d = 1 + ci % (D - 1);
-      int64_t so = P + l * per_layer, qo = mfma_off + l * per_layer_q;
-      for (int dd = 1; dd < d; ++dd) { so += cond_floats(dd, 16, M, 16); qo += cond_floats_mfma(dd, M); }
-      const float* src = params + so;
-      float* dst = prep + qo;
-      const int nf = (1 + d) + 1 + 2 * M;
-      for (int idx = threadIdx.x; idx < nf * 64; idx += blockDim.x) {
-        const int f = idx >> 6, lane = idx & 63, g = lane >> 4, i = lane & 15;
-        float o[4];
-        if (f <= d) {                         // W0 row f (f = 0: the c row)
-          for (int t = 0; t < 4; ++t) o[t] = src[f * 16 + 4 * g + t];
-        } else if (f == d + 1) {              // b0
-          for (int t = 0; t < 4; ++t) o[t] = src[(1 + d) * 16 + 4 * g + t];
-        } else {
-          const int m = (f - (d + 2)) >> 1;
-          const float* Wm = src + (1 + d) * 16 + 16 + m * (256 + 16);
-          if (((f - (d + 2)) & 1) == 0) { for (int t = 0; t < 4; ++t) o[t] = Wm[(4 * g + t) * 16 + i]; }   // A step t
-          else { for (int t = 0; t < 4; ++t) o[t] = Wm[256 + 4 * g + t]; }                               // bias rows 4g+r
+  constexpr int MAXK = 64;
+  // The LAST block normalises the `first` spline (float64); the others snapshot the weights.  The ~40 float64
+  // exp / log calls of the normalisation used to run one after the other on thread 0 of block 0, behind its share of
+  // the copies: 20 us for a kernel every loss evaluation starts with -- now one call per lane, and only the sums
+  // (whose order fixes the result's bits) stay serial.
+  if (blockIdx.x != gridDim.x - 1) {
+    const int nb = gridDim.x - 1;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_params - P; i += (int64_t)nb * blockDim.x)
+      prep[hdr + i] = params[P + i];
+    if (mfma_off > 0) {
+      // MFMA-layout copy of every conditioner (H = P = 16): see conditioner_mfma.
+      const int nc = L * (D - 1);
+      for (int ci = blockIdx.x; ci < nc; ci += nb) {
+        const int l = ci / (D - 1), d = 1 + ci % (D - 1);
+        int64_t so = P + l * per_layer, qo = mfma_off + l * per_layer_q;
+        for (int dd = 1; dd < d; ++dd) { so += cond_floats(dd, 16, M, 16); qo += cond_floats_mfma(dd, M); }
+        const float* src = params + so;
+        float* dst = prep + qo;
+        const int nf = (1 + d) + 1 + 2 * M;
+        for (int idx = threadIdx.x; idx < nf * 64; idx += blockDim.x) {
+          const int f = idx >> 6, lane = idx & 63, g = lane >> 4, i = lane & 15;
+          float o[4];
+          if (f <= d) {                         // W0 row f (f = 0: the c row)
+            for (int t = 0; t < 4; ++t) o[t] = src[f * 16 + 4 * g + t];
+          } else if (f == d + 1) {              // b0
+            for (int t = 0; t < 4; ++t) o[t] = src[(1 + d) * 16 + 4 * g + t];
+          } else {
+            const int m = (f - (d + 2)) >> 1;
+            const float* Wm = src + (1 + d) * 16 + 16 + m * (256 + 16);
+            if (((f - (d + 2)) & 1) == 0) { for (int t = 0; t < 4; ++t) o[t] = Wm[(4 * g + t) * 16 + i]; }   // A step t
+            else { for (int t = 0; t < 4; ++t) o[t] = Wm[256 + 4 * g + t]; }                               // bias rows 4g+r
+          }
+          for (int t = 0; t < 4; ++t) dst[(f * 64 + lane) * 4 + t] = o[t];
         }
-        for (int t = 0; t < 4; ++t) dst[(f * 64 + lane) * 4 + t] = o[t];
       }
     }
+    return;
   }
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
 
-  constexpr int MAXK = 64;
-  double xk[MAXK + 1], yk[MAXK + 1], dl[MAXK + 1];
-  const double total = (hi - lo) - K * min_bin;
-  for (int part = 0; part < 2; ++part) {
-    const float* u = params + part * K;
-    double* pos = part == 0 ? xk : yk;
+  __shared__ double ex[2][MAXK], dl[MAXK + 1], mxs[2];
+  if (threadIdx.x < 2) {
+    const float* u = params + threadIdx.x * K;
     double mx = u[0];
     for (int k = 1; k < K; ++k) mx = fmax(mx, (double)u[k]);
+    mxs[threadIdx.x] = mx;
+  }
+  __syncthreads();
+  const double offset = log(exp(1.0 - min_slope) - 1.0);
+  for (int idx = threadIdx.x; idx < 3 * K + 1; idx += blockDim.x) {
+    if (idx < 2 * K) {
+      const int part = idx / K, k = idx - part * K;
+      ex[part][k] = exp((double)params[part * K + k] - mxs[part]);
+    } else {
+      const int k = idx - 2 * K;
+      const double v = (double)params[2 * K + (periodic && k == K ? 0 : k)] + offset;      // circular: slope K := slope 0
+      dl[k] = fmax(v, 0.0) + log1p(exp(-fabs(v))) + min_slope;
+    }
+  }
+  __syncthreads();
+  __shared__ double xk[MAXK + 1], yk[MAXK + 1];
+  double* td = reinterpret_cast<double*>(prep + tabd_off);     // the same table in float64
+  for (int i = threadIdx.x; i < hdr; i += blockDim.x) { prep[i] = 0.0f; td[i] = 0.0; }
+  const double total = (hi - lo) - K * min_bin;
+  if (threadIdx.x < 2) {       // the knot positions: running sums, in the one order that fixes their bits
+    const int part = threadIdx.x;
+    double* pos = part == 0 ? xk : yk;
     double sum = 0;
-    for (int k = 0; k < K; ++k) sum += exp((double)u[k] - mx);
+    for (int k = 0; k < K; ++k) sum += ex[part][k];
     double run = 0;
     pos[0] = lo;
     for (int k = 0; k < K - 1; ++k) {
-      run += exp((double)u[k] - mx) / sum * total + min_bin;
+      run += ex[part][k] / sum * total + min_bin;
       pos[k + 1] = lo + run;
     }
     pos[K] = hi;
   }
-  const double offset = log(exp(1.0 - min_slope) - 1.0);
-  for (int k = 0; k <= K; ++k) {
-    const double v = (double)params[2 * K + (periodic && k == K ? 0 : k)] + offset;      // circular: slope K := slope 0
-    dl[k] = fmax(v, 0.0) + log1p(exp(-fabs(v))) + min_slope;
-  }
-  double* td = reinterpret_cast<double*>(prep + tabd_off);     // the same table in float64
-  for (int i = 0; i < hdr; ++i) { prep[i] = 0.0f; td[i] = 0.0; }
-  for (int k = 0; k < K; ++k) {
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {      // one bin per thread
     const double bw = xk[k + 1] - xk[k], bh = yk[k + 1] - yk[k], s = bh / bw;
     td[tab_off(F_X0, K) + k] = xk[k];            td[tab_off(F_Y0, K) + k] = yk[k];
     td[tab_off(F_BW, K) + k] = bw;               td[tab_off(F_BH, K) + k] = bh;
@@ -162,7 +182,7 @@ __global__ void prepare_kernel(const float* __restrict__ params, float* __restri
     prep[tab_off(F_D1, K) + k] = (float)dl[k + 1];
     prep[tab_off(F_L2S, K) + k] = (float)(2.0 * log(s));
   }
-  for (int k = 0; k <= K; ++k) {
+  for (int k = threadIdx.x; k <= K; k += blockDim.x) {
     const float big = 1.152921504606846976e18f;      // 2^60
     if (2 * k + 1 < 2 * tab_stride(K)) {
       prep[tab_off(F_XKB, K) + 2 * k] = prep[tab_off(F_XKB, K) + 2 * k + 1] = -(float)xk[k] * big;
@@ -173,6 +193,7 @@ __global__ void prepare_kernel(const float* __restrict__ params, float* __restri
     td[tab_off(F_XK, K) + k] = xk[k];
     td[tab_off(F_YK, K) + k] = yk[k];
   }
+  if (threadIdx.x != 64) return;       // the linear tails (a lane of another wave than the bins')
   double* tld = td + tab_off(F_TAIL, K);
   tld[T_DLO] = dl[0];            tld[T_DHI] = dl[K];
   tld[T_LOG_DLO] = log(dl[0]);   tld[T_LOG_DHI] = log(dl[K]);
@@ -1286,7 +1307,10 @@ extern "C" void cnf_model_destroy(CnfModel* m) {
   if (m->prep) (void)hipFree(m->prep);
   if (m->grad_slabs) (void)hipFree(m->grad_slabs);
   if (m->pwl_stats) (void)hipFree(m->pwl_stats);
-  for (auto& kv : m->pwl_ws) if (kv.second.tables) (void)hipFree(kv.second.tables);
+  for (auto& kv : m->pwl_ws) {
+    if (kv.second.tables) (void)hipFree(kv.second.tables);
+    for (float* p : kv.second.retired) (void)hipFree(p);
+  }
   if (m->prep_event) (void)hipEventDestroy(m->prep_event);
   prof_clear(m);
   delete m;
@@ -1397,6 +1421,7 @@ extern "C" int cnf_model_set_params(CnfModel* m, const float* params, void* stre
   int blocks = (int)((n_w + 255) / 256);
   if (blocks < 1) blocks = 1;
   if (blocks > 256) blocks = 256;
+  blocks += 1;                                  // (+ the block that normalises the `first` spline)
   hipLaunchKernelGGL(prepare_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, m->prep, K,
                      m->n_params, (double)m->cfg.range_min, (double)m->cfg.range_max,
                      (double)m->cfg.min_bin_size, (double)m->cfg.min_knot_slope, m->cfg.dim,
@@ -1559,19 +1584,28 @@ extern "C" int cnf_model_reserve(CnfModel* m, void* stream, int64_t n_sets) {
   std::lock_guard<std::mutex> lock(m->pwl_mu);
   CnfModel::PwlWorkspace& ws = m->pwl_ws[stream];          // value-initialised on first use
   if (ws.sets >= n_sets && n_sets > 0) return CNF_OK;
-  if (ws.tables) {
-    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return CNF_ERR_HIP;   // kernels may still read it
-    (void)hipFree(ws.tables);
+  if (ws.tables && n_sets > 0) {
+    // Growing: the old block is RETIRED, not freed -- a HIP graph captured on this stream has its address baked into
+    // kernel arguments and may be replayed at any later time (a stream synchronisation protects running kernels, not
+    // future replays).  Retired blocks live until cnf_model_destroy or an explicit release (n_sets = 0); reservations
+    // grow geometrically (FlowEngine.reserve), so they add up to less than the current block.
+    ws.retired.push_back(ws.tables);
     ws.tables = nullptr; ws.sets = 0;
   }
-  if (n_sets == 0) { m->pwl_ws.erase(stream); return CNF_OK; }
-  if (hipMalloc((void**)&ws.tables, (size_t)cnf_model_table_bytes(m) * (size_t)n_sets + 64) != hipSuccess) {
+  if (n_sets == 0) {      // explicit release: the caller vouches that nothing (no graph either) uses this stream's tables
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return CNF_ERR_HIP;
+    if (ws.tables) (void)hipFree(ws.tables);
+    for (float* p : ws.retired) (void)hipFree(p);
     m->pwl_ws.erase(stream);
+    return CNF_OK;
+  }
+  if (hipMalloc((void**)&ws.tables, (size_t)cnf_model_table_bytes(m) * (size_t)n_sets + 64) != hipSuccess) {
+    ws.tables = nullptr; ws.sets = 0;        // (calls on this stream fall back to the MLP kernels; retired blocks stay)
     return CNF_ERR_NOMEM;
   }
   // the stamp of cond_uniform_kernel starts at 0; epochs count from 1
   if (hipMemset(reinterpret_cast<char*>(ws.tables) + (size_t)cnf_model_table_bytes(m) * (size_t)n_sets, 0, 64) != hipSuccess) {
-    (void)hipFree(ws.tables); m->pwl_ws.erase(stream);
+    (void)hipFree(ws.tables); ws.tables = nullptr; ws.sets = 0;
     return CNF_ERR_HIP;
   }
   ws.sets = n_sets; ws.epoch = 0;

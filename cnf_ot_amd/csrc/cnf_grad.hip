@@ -724,8 +724,8 @@ __device__ __forceinline__ double stat_scale(uint32_t amax_bits) {
 // the largest |ybar|, |ldbar| of a call (bit pattern of a non-negative float: ordered like the integers)
 __global__ __launch_bounds__(256) void adjoint_max_kernel(const float* __restrict__ ybar, int64_t n_y,
                                                          const float* __restrict__ ldbar, int64_t n_l, uint32_t* out) {
-  uint32_t m = 0;
-  auto take = [&](float v) { const uint32_t b = __float_as_uint(v) & 0x7fffffffu; m = (b > m && b < 0x7f800000u) ? b : m; };
+  uint32_t m = 0, bad = 0;      // bad: an Inf / NaN adjoint was seen -> out[1] (the table backward then answers NaN, like the MLP backward)
+  auto take = [&](float v) { const uint32_t b = __float_as_uint(v) & 0x7fffffffu; bad |= b >= 0x7f800000u ? 1u : 0u; m = (b > m && b < 0x7f800000u) ? b : m; };
   auto scan = [&](const float* __restrict__ p, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {            // 16-byte loads, four in flight per thread
@@ -749,6 +749,7 @@ __global__ __launch_bounds__(256) void adjoint_max_kernel(const float* __restric
     const uint32_t mm = a01 > a23 ? a01 : a23;
     if (mm) atomicMax(out, mm);
   }
+  if (__builtin_amdgcn_ballot_w64(bad != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(out + 1, 1u);
 }
 
 struct VjpPwlArgs {
@@ -760,7 +761,7 @@ struct VjpPwlArgs {
   const float* tables;   // [n_slices][L][PWL_TBL]
   stat_t* stats;         // [n_slices][L][PWL_NPIECE][PWL_STAT] fixed point, zero on entry
   stat_t* coarse;        // the same shape at 2^-32 of the scale: terms too large for `stats` (ill-conditioned flows)
-  const uint32_t* amax;  // bits of the largest |adjoint| of the call (adjoint_max_kernel)
+  uint32_t* amax;        // [0] bits of the largest |adjoint| of the call (adjoint_max_kernel), [1] non-finite flag
   float* slabs;          // slab b (this workgroup's): zeroed here, its first GP entries receive the `first` spline's
   int64_t n_params;      // per-bin adjoint sums (one owner per slab: a fixed summation order)
   int64_t B, slice_len;
@@ -925,7 +926,14 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
 #pragma unroll
           for (int m2 = 0; m2 < 2 * K; ++m2) big = fmaxf(big, fabsf(tb[m2]));
           big *= fmaxf(1.0f, fabsf(du));
-          if (p < PWL_ACC_W && (double)big * fx_scale < 1125899906842624.0) {
+          // (fmaxf drops NaNs: the sum of the terms does not) a non-finite term poisons the call's gradient, like the
+          // float accumulation of the MLP backward would -- the fixed-point sums cannot carry it themselves
+          float chk = (sb0 + sb1) * du;
+#pragma unroll
+          for (int m2 = 0; m2 < 2 * K; ++m2) chk += tb[m2];
+          if (!(fabsf(chk) < INFINITY) || !(big < INFINITY)) {
+            atomicOr(a.amax + 1, 1u);
+          } else if (p < PWL_ACC_W && (double)big * fx_scale < 1125899906842624.0) {
             typedef stat_t __attribute__((address_space(3))) * lds_q_ptr;
             lds_q_ptr d3 = (lds_q_ptr)(uintptr_t)(uint32_t)(uintptr_t)(acc + (l * PWL_ACC_W + p) * PWL_STAT_LDS);
             auto add = [&](int e, float x) {
@@ -992,7 +1000,7 @@ struct StatsFinishArgs {
   const float* tables;
   stat_t* stats;
   stat_t* coarse;
-  const uint32_t* amax;
+  const uint32_t* amax;  // [0] largest adjoint, [1] non-finite flag
   float* slabs;          // [first_slab + n_slices * L][n_params]
   int64_t n_params;
   int32_t L, first_slab;
@@ -1095,6 +1103,9 @@ __global__ __launch_bounds__(256) void pwl_stats_finish_kernel(const StatsFinish
   for (int64_t i = tid; i < a.n_params; i += blockDim.x) {
     const int64_t o = i - base;
     slab[i] = (o >= 0 && o < NW) ? (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]) : 0.0f;
+  }
+  if (a.amax[1] != 0) {      // a non-finite adjoint or term somewhere in the call: the gradient says so
+    for (int64_t i = tid; i < a.n_params; i += blockDim.x) slab[i] = __int_as_float(0x7fc00000);
   }
 }
 
@@ -1583,7 +1594,7 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     a.tables = tables; a.stats = stats; a.coarse = coarse; a.amax = amax; a.slabs = m->grad_slabs; a.n_params = m->n_params;
     a.B = (B - first) < ns * slice_len ? (B - first) : ns * slice_len;
     a.slice_len = slice_len; a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps;
-    if (hipMemsetAsync(amax, 0, 4, stream) != hipSuccess) return CNF_ERR_HIP;
+    if (hipMemsetAsync(amax, 0, 8, stream) != hipSuccess) return CNF_ERR_HIP;
     hipLaunchKernelGGL(adjoint_max_kernel, dim3((unsigned)(m->num_cus * 2)), dim3(256), 0, stream, a.ybar, a.ybar ? 2 * a.B : 0, a.ldbar,
                        a.ldbar ? a.B : 0, amax);
     const int64_t tiles = ns * tps;

@@ -45,3 +45,29 @@ def all_reduce_sums(sums: torch.Tensor, shard: Shard) -> torch.Tensor:
     import torch.distributed as dist
     dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=shard.group)
   return sums
+
+
+def broadcast_params(params, src: int = 0, shard: Optional[Shard] = None) -> None:
+  """Replicate the parameters of rank `src` (the multi-GPU init step) and tell the engines: torch.distributed
+  collectives write in place WITHOUT bumping the tensor's version counter, so an engine that skips unchanged
+  parameters (FlowEngine.load(assume_unchanged=True)) would keep computing with the old ones."""
+  shard = shard if shard is not None else current_shard()
+  flat = params.flat if hasattr(params, "flat") else params
+  if shard.world > 1:
+    import torch.distributed as dist
+    dist.broadcast(flat, src=src, group=shard.group)
+  from .flows import mark_updated
+  mark_updated(flat)
+
+
+def all_reduce_params(params, average: bool = True, shard: Optional[Shard] = None) -> None:
+  """Sum (or average) the parameters over the ranks in place, and mark them as written (see broadcast_params)."""
+  shard = shard if shard is not None else current_shard()
+  flat = params.flat if hasattr(params, "flat") else params
+  if shard.world > 1:
+    import torch.distributed as dist
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=shard.group)
+    if average:
+      flat.div_(shard.world)
+  from .flows import mark_updated
+  mark_updated(flat)

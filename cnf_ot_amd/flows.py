@@ -96,16 +96,20 @@ class FlowEngine:
       self._h = None
 
   # -- parameters ------------------------------------------------------------
-  def load(self, params) -> "FlowEngine":
-    """cnf_model_set_params: prepare the `first` table + snapshot the weights.
-    Skipped when `params` is the very tensor that is already loaded and nothing
-    has written to it since (torch's version counter; in-place writers that
-    bypass torch -- Adam.apply through the C ABI -- call `mark_updated`)."""
+  def load(self, params, assume_unchanged: bool = False) -> "FlowEngine":
+    """cnf_model_set_params: prepare the `first` table + snapshot the weights -- on EVERY call by default (one small
+    kernel on the stream), like passing `params` to a pure function.
+    assume_unchanged=True (opt-in; `FlowModel(assume_unchanged_params=True)` turns it on for model.apply.*): skip the
+    preparation when `params` is the very tensor that is already loaded and nothing visible has written to it since --
+    same address, same torch version counter, same write epoch (`mark_updated`, bumped by Adam.apply).  NOT every
+    in-place writer is visible this way: torch.distributed collectives (all_reduce, broadcast), writes through
+    `.data` and kernels of other libraries leave the version counter alone -- after those call `mark_updated(flat)`
+    (cnf_ot_amd.distributed.broadcast_params / all_reduce_params do) or load without the flag."""
     flat = flatten(self.cfg, params, self.device)
     # the same memory (this engine keeps `_flat` alive, so its address cannot have been recycled), same torch
     # version (aliases made by detach() share the counter), no C-side write since
     key = (flat.data_ptr(), flat._version, _WRITE_EPOCH.get(flat.data_ptr(), 0))
-    if self._flat is not None and key == self._flat_key:
+    if assume_unchanged and self._flat is not None and key == self._flat_key:
       return self
     with torch.cuda.device(self.device):
       _capi.check(self.lib.cnf_model_set_params(self._h, flat.data_ptr(), _stream_ptr(self.device)),
@@ -588,7 +592,7 @@ class _Apply:
       device = like.device
     if device is None or device.type != "cuda":
       device = torch.device("cuda", torch.cuda.current_device())
-    return self._m.engine(device).load(params)
+    return self._m.engine(device).load(params, assume_unchanged=self._m.assume_unchanged_params)
 
   # conditional.py:316-321
   def log_prob(self, params, value, cond=None):
@@ -651,11 +655,13 @@ class FlowModel:
   """What the reference's driver holds after
   ``hk.without_apply_rng(hk.multi_transform(RQSFlow(...)))`` (solvers.py:41-48)."""
 
-  def __init__(self, cfg: FlowConfig, rng: str = "philox"):
+  def __init__(self, cfg: FlowConfig, rng: str = "philox", assume_unchanged_params: bool = False):
     if rng not in ("philox", "threefry"):
       raise ValueError("rng must be 'philox' (the build's own stream) or 'threefry' (jax.random.normal's)")
     self.cfg = cfg
     self.rng = rng
+    # model.apply.*(params, ...) re-prepares `params` on every call unless this is set (FlowEngine.load)
+    self.assume_unchanged_params = bool(assume_unchanged_params)
     self._engines = {}
     a = _Apply(self)
     self.apply = Flow(a.log_prob, a.sample, a.sample_and_log_prob, a.forward, a.inverse,

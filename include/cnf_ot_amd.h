@@ -109,8 +109,11 @@ int cnf_model_set_params(CnfModel *m, const float *params, void *stream);
  * bytes) per time-slice and condition; the fused loss terms need up to three
  * sets per slice (t - dt/2, t + dt/2, t).  cnf_model_reserve(m, stream, n_sets)
  * makes room for n_sets sets for calls on `stream` (grows only; n_sets = 0
- * releases it).  It allocates and may synchronise `stream`: call it outside
- * graph capture.  Compute calls never allocate: a call with more slices than
+ * releases it).  It allocates: call it outside graph capture.  A block that a
+ * larger reservation replaces stays allocated until cnf_model_destroy (or the
+ * release), so a graph captured on the smaller one can still be replayed; the
+ * release (n_sets = 0) synchronises `stream`, frees everything and invalidates
+ * graphs captured on this model's table path.  Compute calls never allocate: a call with more slices than
  * the reservation holds is processed in chunks, and without a (useful)
  * reservation the same result comes from the MLP kernels.  2 048 sets cover the
  * largest chunk a call is ever split into. */

@@ -417,6 +417,38 @@ def test_pass_vjp_table_form_matches_mlp_backward(dev, to_base, L, S, Bs):
     assert (g2[lo:hi] - g0[lo:hi]).abs().max().item() <= 1e-4 * max(ref, 1e-3 * g0.abs().max().item()), (lo, hi)
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_table_backward_does_not_hide_non_finite_adjoints(dev, bad):
+  """The fixed-point statistics of the table backward cannot carry a NaN or an Inf (an integer sum, range tests that
+  drop what they cannot represent): a call that meets one flags it and answers with a NaN gradient -- what the float
+  accumulation of the MLP backward gives, and what a training loop looks for.  The next call is clean again."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  cfg = FlowConfig(dim=2)
+  params = Params.random(cfg, 0.2, seed=5, device=dev)
+  eng = FlowEngine(cfg, dev).load(params)
+  S, Bs = 4, 3000
+  gen = torch.Generator(device="cpu").manual_seed(3)
+  pts = torch.randn(S * Bs, 2, generator=gen).to(dev)
+  ts = torch.linspace(0.1, 0.9, S).to(dev)
+  ybar = torch.randn(S * Bs, 2, generator=gen).to(dev)
+  good = ybar.clone()
+  ybar[1234, 1] = bad
+  eng.set_pwl(2)
+  g = torch.zeros(cfg.param_count(), device=dev)
+  eng.pass_vjp(pts, ts, ybar, None, False, grad=g, want_xbar=False)
+  assert eng.last_path() == "tables"
+  assert not torch.isfinite(g).all()
+  eng.set_pwl(0)
+  g_mlp = torch.zeros(cfg.param_count(), device=dev)
+  eng.pass_vjp(pts, ts.repeat_interleave(Bs)[:, None], ybar, None, False, grad=g_mlp, want_xbar=False)
+  assert not torch.isfinite(g_mlp).all()
+  eng.set_pwl(2)
+  g2 = torch.zeros(cfg.param_count(), device=dev)
+  eng.pass_vjp(pts, ts, good, None, False, grad=g2, want_xbar=False)
+  assert torch.isfinite(g2).all() and g2.abs().max().item() > 0
+  eng.set_pwl(1)
+
+
 @pytest.mark.parametrize("subtype", ["free", "obstacle", "rwpo"])
 def test_value_and_grad_through_the_table_backward(dev, subtype, monkeypatch):
   """ot_loss_fn at dim 2 with its terms composed from table-path launches + cnf_pass_vjp on the tables

@@ -395,6 +395,72 @@ def test_entry_points_are_graph_capturable(dev):
   eng.set_pwl(1)
 
 
+def test_graph_replay_survives_a_larger_reservation(dev):
+  """A HIP graph captured on the table path has the workspace address baked into its kernel arguments.  Growing the
+  stream's reservation afterwards (an eager call with more slices) must not free that block: the replay that follows
+  would read and write freed memory (cnf_model_reserve retires outgrown blocks instead of freeing them)."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  cfg = FlowConfig(dim=2)
+  eng = FlowEngine(cfg, dev).load(Params.random(cfg, 0.2, seed=9, device=dev))
+  eng.set_pwl(2)
+  S, Bs = 4, 4096
+  x = eng.normal(1, S * Bs)
+  t = torch.linspace(0.2, 0.8, S, device=dev)
+  y = torch.empty(S * Bs, 2, device=dev); lp = torch.empty(S * Bs, device=dev)
+  side = torch.cuda.Stream(device=dev)
+  side.wait_stream(torch.cuda.current_stream(dev))
+  with torch.cuda.stream(side):
+    small = eng.reserve(S)
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph, stream=side):
+    eng.sample_logprob(x, t, out=y, logp_out=lp)
+    assert eng.last_path() == "tables"
+  graph.replay(); torch.cuda.synchronize()
+  y0, lp0 = y.clone(), lp.clone()
+  # an eager call on the SAME stream with many more slices: the engine grows the reservation
+  with torch.cuda.stream(side):
+    S2 = 8 * small
+    x2 = eng.normal(3, S2 * 1024)
+    eng.sample_logprob(x2, torch.linspace(0.0, 1.0, S2, device=dev))
+    assert eng.lib.cnf_model_reserved(eng._h, side.cuda_stream) > small
+    # churn the allocator so that a freed block would have been handed out again and overwritten
+    junk = [torch.full((1 << 20,), float("nan"), device=dev) for _ in range(8)]
+  torch.cuda.synchronize()
+  y.zero_(); lp.zero_()
+  graph.replay(); torch.cuda.synchronize()
+  assert torch.equal(y, y0) and torch.equal(lp, lp0)
+  del junk
+  eng.set_pwl(1)
+
+
+def test_load_reprepares_unless_told_the_parameters_are_unchanged(dev):
+  """FlowEngine.load prepares the parameters on every call: writers torch does not see (collectives, `.data`, other
+  libraries' kernels) leave the version counter alone, and an engine that skipped "unchanged" parameters would go on
+  computing with the old weights.  The skip is opt-in (assume_unchanged=True) and `mark_updated` is its escape hatch."""
+  from cnf_ot_amd import FlowConfig, FlowModel, Params
+  from cnf_ot_amd.flows import mark_updated
+  cfg = FlowConfig(dim=2)
+  params = Params.random(cfg, 0.2, seed=3, device=dev)
+  x = torch.randn(4096, 2, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+  c = torch.tensor([0.4], device=dev)
+  model = FlowModel(cfg)
+  lp0 = model.apply.log_prob(params, x, c).clone()
+  v = params.flat._version
+  params.flat.data.mul_(1.5)                       # a write torch's version counter does not record
+  assert params.flat._version == v
+  lp1 = model.apply.log_prob(params, x, c).clone()
+  assert (lp1 - lp0).abs().max().item() > 1e-3     # default: re-prepared, the new weights are used
+  fast = FlowModel(cfg, assume_unchanged_params=True)
+  a0 = fast.apply.log_prob(params, x, c).clone()
+  assert torch.equal(a0, lp1)
+  params.flat.data.mul_(1.0 / 1.5)
+  stale = fast.apply.log_prob(params, x, c).clone()
+  assert torch.equal(stale, a0)                    # the documented hazard of the opt-in ...
+  mark_updated(params.flat)
+  fresh = fast.apply.log_prob(params, x, c).clone()
+  assert (fresh - lp0).abs().max().item() <= 1e-5  # ... and its escape hatch
+
+
 def test_compute_calls_never_allocate(dev):
   """A compute call never grows the table workspace: on a stream WITHOUT a
   reservation, captured into a graph (where an allocation would fail the
