@@ -125,6 +125,9 @@ def cpu_baseline(params64, seconds, threads=0):
     # sustains, so a few batches are not enough to rank the candidates
     cands = sorted({c for c in (affinity if affinity <= 128 else None, _cgroup_cpus(), 64, 32, 16)
                     if c and c <= affinity}, reverse=True)
+    if affinity > 128:
+      print(f"cpu_baseline: affinity_cores not tried: {affinity} > 128 (the box schedules a share of the host; "
+            f"candidates {cands})", file=sys.stderr, flush=True)
     for c in cands:
       oracle.set_num_threads(c)
       oracle.sample_logprob(ocfg, params64, noise, [0.5])
@@ -146,7 +149,7 @@ def cpu_baseline(params64, seconds, threads=0):
       break
   return {
     "value": n * BATCH / dt, "unit": "samples/s", "cores": oracle.num_threads(),
-    "kind": "port", "affinity_cores": affinity,
+    "kind": "port", "affinity_cores": affinity, "affinity_cores_tried": affinity <= 128 or threads == affinity,
     "threads_tried": {str(k): v for k, v in tried.items()},
     "sample": f"{n} batches of {BATCH} (float64 C oracle, OpenMP, {dt:.1f} s)",
   }
@@ -458,7 +461,7 @@ def main():
       "samples_per_launch": k_samples, "bytes_per_sample": BYTES_PER_SAMPLE,
       "table_build_ms_per_launch": b_dur * 1e3,
       "timing": "HIP events recorded by the library on the launch stream around each kernel launch "
-                "(cnf_model_set_profiling), same calls as the timed region, run right after it",
+                "(cnf_model_set_profiling, include/cnf_ot_amd_debug.h), same calls as the timed region, run right after it",
       "alu_executed": {"flop_per_sample": exec_flop, "achieved": executed_tflops,
                        "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": executed_tflops / PEAK_FP32_TFLOPS},
       "alu_reference_formulation": {"flop_per_sample": FLOP_PER_SAMPLE, "achieved": achieved_tflops,

@@ -91,7 +91,7 @@ SYMBOLS = {
   "cnf_build_arch": (ctypes.c_char_p, []),
   "cnf_config_supported": (ctypes.c_int, [_CFG]),
 }
-# internal knobs (not part of the public header)
+# test / measurement knobs: include/cnf_ot_amd_debug.h (not part of the drop-in boundary)
 _INTERNAL = {
   "cnf_model_set_fast_math": (ctypes.c_int, [_P, ctypes.c_int]),
   "cnf_model_set_samples_per_lane": (ctypes.c_int, [_P, ctypes.c_int]),

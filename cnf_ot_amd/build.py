@@ -14,7 +14,7 @@ SRC_DIR = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcnf_ot_amd.so")
 SOURCES = ["cnf_flow.hip", "cnf_grad.hip"]
-HEADERS = ["cnf_device.h", "cnf_common.h", "cnf_backward.h", "cnf_pwl.h",
+HEADERS = ["cnf_device.h", "cnf_common.h", "cnf_backward.h", "cnf_pwl.h", "cnf_pwl_build.h",
            os.path.join("..", "..", "include", "cnf_ot_amd.h")]
 VARIANT_PATH = os.path.join(LIB_DIR, "BUILD_VARIANT")     # "full" or "minimal": what the .so in tree contains
 ARCH = "gfx950"

@@ -16,7 +16,7 @@
 //    per-lane bin index.
 #include "cnf_common.h"
 #include <cstdlib>
-#include "cnf_pwl.h"
+#include "cnf_pwl_build.h"
 
 #include <math.h>
 #include <new>
@@ -613,14 +613,6 @@ __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, 
       lo0 = odd ? olo_o : olo_f;
       lo1 = odd ? olo_f : olo_o;
     } else {
-#ifdef CNF_PWL_ROWS_OLD             /* experiment switch: all 16 logits up front, slopes selected with masks */
-      table_spline<K, INV, FAST, v2f>(tab, uf, sc, of, ld);
-      acc += ld;
-      v2f th[PWL_P];
-      pwl_eval<LROWS>(tl, gl, TO_BASE ? of : uf, th, general);
-      if (!SHIFT_FREE_OK || __builtin_amdgcn_ballot_w64(general) != 0) cond_spline_masked<K, INV, FAST, false>(th, uo, sc, oo, ld);
-      else cond_spline_masked<K, INV, FAST, true>(th, uo, sc, oo, ld);
-#else
       // base -> data: the conditioner sees the layer's INPUT, so its table search and row reads (a chain of three
       // dependent LDS round trips) are issued first and complete under the arithmetic of the `first` spline
       PwlRows rr;
@@ -634,11 +626,7 @@ __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, 
       // their log|f'| (the derivative itself) and the product goes through one v_log_f32.  The conditioned
       // factor is bounded there (slope logits in [-3, 40], bins >= 1e-4 of a range of 20: ~1e-9 .. 1e6), so the
       // product leaves the fp32 range only for a `first` spline with derivatives beyond 1e-29 .. 1e32.
-#ifdef CNF_PWL_LOGPROD              /* experiment switch: measured within noise (1.477 vs 1.480 ms), off */
-      constexpr bool LOGPROD = SHIFT_FREE_OK;
-#else
-      constexpr bool LOGPROD = false;
-#endif
+      constexpr bool LOGPROD = false;     // (measured within noise: 1.477 vs 1.480 ms per launch -- off)
       v2f larg = splat<v2f>(1.0f);
       if constexpr (LOGPROD) {
         table_spline<K, INV, FAST, v2f, true>(tab, uf, sc, of, larg);
@@ -655,11 +643,7 @@ __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, 
         ta = pwl_slope_pair<LROWS>(rr.ra, gl, rr.pa, ka, rr.dua);
         tb = pwl_slope_pair<LROWS>(rr.rb, gl, rr.pb, kb, rr.dub);
       };
-#ifdef CNF_PWL_FORCE_GENERAL        /* experiment switch: never the shift-free form */
-      if (true)
-#else
       if (!SHIFT_FREE_OK || __builtin_amdgcn_ballot_w64(general) != 0)      // wave-uniform: a lane's cell is marked
-#endif
       {       // marked cells (ill-conditioned pieces, far-out inputs): the general form, and its own logarithm
         cond_spline_rows<K, INV, FAST, false, false>(qa, qb, slopes, uo, sc, oo, ld);
         if constexpr (LOGPROD) { const v2f lg = Math<FAST>::log(larg); ld += INV ? -lg : lg; }
@@ -667,7 +651,6 @@ __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, 
         cond_spline_rows<K, INV, FAST, true, LOGPROD>(qa, qb, slopes, uo, sc, oo, ld);
         if constexpr (LOGPROD) { const v2f lg = Math<FAST>::log(larg * ld); ld = INV ? -lg : lg; }
       }
-#endif
     }
     acc += ld;
     u0 = odd ? oo : of;
@@ -729,9 +712,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
   // The points of tile i + 1 are requested before tile i is computed: measured (r02e PMC) a wave spent half its
   // time in s_waitcnt, much of it on this one load issued right in front of its first use.
   [[maybe_unused]] f4 xn = {0.f, 0.f, 0.f, 0.f};
-#ifndef CNF_PWL_NO_PREFETCH
   if (t0 < t1) xn = tile_points(tile_of(t0));
-#endif
   for (int tile = t0; tile < t1; ++tile) {
     const Tile tl = tile_of(tile);
     const int slice = tl.slice;
@@ -743,13 +724,9 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
     }
     const bool full = tl.valid == PWL_TS;
     const bool v0 = (int)lane2 < tl.valid, v1 = (int)lane2 + 1 < tl.valid;
-#ifdef CNF_PWL_NO_PREFETCH          /* experiment switch */
-    const f4 x = tile_points(tl);
-#else
     const f4 x = xn;
     if (tile + 1 < t1) xn = tile_points(tile_of(tile + 1));
     __builtin_amdgcn_sched_barrier(0);
-#endif
     v2f u0 = {x[0], x[2]}, u1 = {x[1], x[3]};
 
     v2f base = splat<v2f>(0.0f);
@@ -1439,9 +1416,7 @@ extern "C" int cnf_model_set_params(CnfModel* m, const float* params, void* stre
 }
 
 
-#ifndef CNF_MFMA_SMALL_WAVES
-#define CNF_MFMA_SMALL_WAVES 4        /* waves of single-lane work per SIMD up to which use_mfma = 2 picks MFMA */
-#endif
+constexpr int CNF_MFMA_SMALL_WAVES = 4;        // waves of single-lane work per SIMD up to which use_mfma = 2 picks MFMA
 
 // Two samples per lane (packed fp32) once the batch fills every SIMD with at
 // least one wave of sample pairs; one sample per lane below that.
@@ -1644,8 +1619,7 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
     return (size_t)(((cnf::hdr_floats(5) + 3) & ~3) + L * cnf::pwl_ltbl(lrows)) * sizeof(float) +
            (precise ? precise_lds_bytes(5) : 0);
   };
-  static const int env_window = [] { const char* e = getenv("CNF_PWL_WINDOW"); return e ? atoi(e) : 0; }();   // experiment switch
-  const bool full = !env_window && lds_for(cnf::PWL_NPIECE) <= 160 * 1024;
+  const bool full = lds_for(cnf::PWL_NPIECE) <= 160 * 1024;
   size_t lds = lds_for(full ? cnf::PWL_NPIECE : cnf::PWL_LROWS);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
   const int64_t slice_len = c_block < B ? c_block : B;
@@ -1657,14 +1631,9 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
   // Measured (MI355X, 256 x 65 536): the kernel is VALU-bound and runs best at 4 waves per SIMD -- one
   // 1024-thread workgroup per CU 58.9 G samples/s; 6 waves (3 x 512) 56.9; 2 waves 47.8.  Asking for at
   // least 82 KB of LDS keeps a second workgroup off the CU.
-  // experiment switches (scripts/exp_occupancy.sh): CNF_PWL_THREADS = workgroup size, CNF_PWL_MIN_LDS_KB = LDS asked
-  // for per workgroup (how many workgroups share a CU)
-  static const int env_threads = [] { const char* e = getenv("CNF_PWL_THREADS"); return e ? atoi(e) : 0; }();
-  static const int env_lds_kb = [] { const char* e = getenv("CNF_PWL_MIN_LDS_KB"); return e ? atoi(e) : 0; }();
-  static const int env_bpc = [] { const char* e = getenv("CNF_PWL_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
-  const int pwl_threads = env_threads >= 64 && env_threads <= cnf::PWL_MAX_THREADS && env_threads % 64 == 0
-                              ? env_threads : cnf::PWL_MAX_THREADS;
-  const size_t pwl_min_lds = env_lds_kb > 0 ? (size_t)env_lds_kb * 1024 : 82 * 1024;
+  // (profiles/r02_experiments: other workgroup sizes and LDS requests -- 2 / 4 / 6 waves per SIMD -- were all slower)
+  const int pwl_threads = cnf::PWL_MAX_THREADS;
+  const size_t pwl_min_lds = 82 * 1024;
   const int64_t PWL_TS = 2 * pwl_threads;
   const int64_t tps = (slice_len + PWL_TS - 1) / PWL_TS;
   const int64_t total = n_slices * tps;
@@ -1726,7 +1695,7 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
     a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps; a.aux_mode = aux_mode;
     a.gate = flag; a.gate_epoch = epoch; a.gate_want = 0;        // tables: only if no block stamped a difference
     const int64_t tiles = ns * tps;
-    const int64_t want = (int64_t)m->num_cus * (env_bpc > 0 ? env_bpc : 1);
+    const int64_t want = (int64_t)m->num_cus;
     const int64_t grid = tiles < want ? tiles : want;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(pwl_threads), lds, stream, a);
     ps.done();

@@ -14,7 +14,6 @@
 //     the result is deterministic); grad_finish_kernel sums the slabs.
 // Built for the reference's network only: hidden 16, 2 hidden layers, 5 bins.
 #include "cnf_backward.h"
-#define CNF_PWL_NO_BUILDER
 #include "cnf_pwl.h"
 
 #include <math.h>
@@ -916,7 +915,6 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
         float ucond_bar = fmaf(rowk[0] * LN2, sb0, rowk[1] * LN2 * sb1);
 #pragma unroll
         for (int m2 = 0; m2 < 2 * K; ++m2) ucond_bar = fmaf(S[m2], tb[m2], ucond_bar);
-#ifndef CNF_VJP_PWL_NO_ATOMICS     /* experiment switch: what the accumulation costs */
         // The adjoints of a softmax group's logits sum to zero: the last width and the last height entry are not
         // accumulated (pwl_stats_finish_kernel restores them as minus the sum of the other four) -- 20 atomic
         // instructions per layer.  One range test per layer decides between the straight-line form (every term
@@ -954,7 +952,6 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
             accumulate(slice, l, p, 2 * K + kk + 1, sb1); accumulate(slice, l, p, PWL_P + 2 * K + kk + 1, du * sb1);
           }
         }
-#endif
         float ub_f = 0.0f;
         if (TO_BASE) ob_f += ucond_bar; else ub_f = ucond_bar;
         ub_f += table_spline_bwd<K, INV, true>(tab, in_f[step], out_f[step], ob_f, ld_bar, sc, fa.Wb, fa.Hb, fa.Db);

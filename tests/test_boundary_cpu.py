@@ -16,16 +16,23 @@ from cnf_ot_amd.params import FlowConfig, Params, param_spec, from_tree, flatten
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _declared(header):
+  with open(os.path.join(ROOT, "include", header)) as f:
+    text = f.read()
+  text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+  return set(re.findall(r"\b(cnf_[a-z_0-9]+)\s*\(", text))
+
+
 def test_library_exports_every_declared_symbol():
-  with open(os.path.join(ROOT, "include", "cnf_ot_amd.h")) as f:
-    header = f.read()
-  header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-  declared = set(re.findall(r"\b(cnf_[a-z_0-9]+)\s*\(", header))
-  assert declared, "no declarations parsed"
-  assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+  """Both headers: the drop-in boundary (cnf_ot_amd.h <-> _capi.SYMBOLS) and the test / measurement knobs
+  (cnf_ot_amd_debug.h <-> _capi._INTERNAL) -- nothing is bound that no header declares."""
   lib = _capi.lib()
-  for name in declared:
-    assert hasattr(lib, name), name
+  for header, table in (("cnf_ot_amd.h", _capi.SYMBOLS), ("cnf_ot_amd_debug.h", _capi._INTERNAL)):
+    declared = _declared(header)
+    assert declared, header
+    assert declared == set(table), (header, declared ^ set(table))
+    for name in declared:
+      assert hasattr(lib, name), name
 
 
 def test_c_param_count_and_support_table():
