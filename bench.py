@@ -197,6 +197,14 @@ def per_call_section(eng, model, params, noise1, t_slices, y1, lp1, dev):
   model.assume_unchanged_params = False
   out["model_apply_eager_assume_unchanged"] = {"ms_per_call": dt * 1e3, "value": BATCH / dt,
                                                "note": "the same with FlowModel(assume_unchanged_params=True)"}
+  dt = loop(lambda i: model.apply.sample_and_log_prob(params, cond=cond_b1[i % len(cond_b1)], seed=1000 + i,
+                                                       sample_shape=(BATCH,)))
+  out["model_apply_seeded"] = {"ms_per_call": dt * 1e3, "value": BATCH / dt, "kernel": eng.last_path(),
+                               "bytes_per_sample": 4 * (DIM + 1), "hbm_frac": 4 * (DIM + 1) * BATCH / dt / 1e9 / PEAK_HBM_GBS,
+                               "note": "model.apply.sample_and_log_prob(params, cond=[B,1], seed=) -- the reference's "
+                                       "form with the base draw inside the call (conditional.py:376-402): "
+                                       "cnf_sample_logprob_seeded, noise drawn in the flow kernel; algorithmic bytes "
+                                       "12 per sample (y and log_prob out, nothing in)"}
   try:       # the same launch-bound loop captured once into a HIP graph and replayed (entry points only enqueue)
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))

@@ -61,6 +61,7 @@ SYMBOLS = {
   "cnf_inverse_logdet": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
   "cnf_log_prob": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _P]),
   "cnf_sample_logprob": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
+  "cnf_sample_logprob_seeded": (ctypes.c_int, [_P, _U64, _I64, _I64, _P, _I64, _P, _P, _I64, _P]),
   "cnf_forward_logdet_f64": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
   "cnf_inverse_logdet_f64": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
   "cnf_log_prob_f64": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _P]),

@@ -50,6 +50,10 @@ template <class R> struct FlowArgsT {
   // (log_prob(j) - log_prob(j + 1)) * fd_inv_dx.  fd2 = 0: off.
   int32_t fd2;
   R fd_h, fd_inv_dx;
+  // in == null (float32, base -> data only; cnf_sample_logprob_seeded): the points are base noise drawn in the kernel,
+  // sample i = stream sample first_sample + (i / c_block) * slice_stride + i % c_block of the cnf_fill_normal stream
+  uint64_t seed;
+  int64_t first_sample, slice_stride;
 };
 typedef FlowArgsT<float> FlowArgs;
 typedef FlowArgsT<double> FlowArgsD;
@@ -222,6 +226,61 @@ __device__ __forceinline__ void tile_load(const R* __restrict__ g, R* U, int D, 
     U[d * TS + s] = e < n_el ? g[base + e] : (R)0;
   }
 }
+
+// One tile of base noise straight into LDS: the tile's TS*D stream elements are
+// contiguous; a thread draws whole Philox blocks (4 normals) and scatters them.
+__device__ __forceinline__ void tile_noise(uint64_t seed, uint64_t first_element, float* U, int D, uint32_t magic,
+                                           int TS, int64_t n_valid_samples, int nthreads = TILE) {
+  const int n_el = (int)(n_valid_samples < TS ? n_valid_samples : TS) * D;
+  const uint64_t blk0 = first_element >> 2;
+  const int n_blk = (int)(((first_element + (uint64_t)(TS * D) - 1) >> 2) - blk0) + 1;
+  for (int q = threadIdx.x; q < n_blk; q += nthreads) {
+    const uint64_t blk = blk0 + (uint64_t)q;
+    float z[4];
+    philox_normals4(seed, blk, z);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t e = (int64_t)((blk << 2) + r) - (int64_t)first_element;
+      if (e >= 0 && e < TS * D) {
+        const int s = magic ? (int)__umulhi((uint32_t)e, magic) : (int)e, d = (int)e - s * D;
+        U[d * TS + s] = e < n_el ? z[r] : 0.0f;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float normal_at(uint64_t seed, uint64_t e) {     // element e of the cnf_fill_normal stream
+  float z[4];
+  philox_normals4(seed, e >> 2, z);
+  return z[e & 3];
+}
+
+// The tile of a seeded flow call (FlowArgsT::in == null): one contiguous run of the stream where the tile lies in
+// one slice (or the slices follow each other in the stream), element by element otherwise.
+__device__ __forceinline__ void tile_noise_flow(const FlowArgsT<float>& a, float* U, int D, uint32_t magic, int TS,
+                                                int64_t tile_start, int nthreads) {
+  const int64_t left = a.B - tile_start;
+  const int64_t last = tile_start + (left < TS ? left : TS) - 1;
+  const bool one = a.c_block >= a.B;
+  const int64_t s0 = one ? 0 : tile_start / a.c_block, s1 = one ? 0 : last / a.c_block;
+  if (s0 == s1 || a.slice_stride == a.c_block) {
+    const int64_t st = a.first_sample + s0 * a.slice_stride + (tile_start - s0 * a.c_block);
+    tile_noise(a.seed, (uint64_t)st * (uint64_t)D, U, D, magic, TS, left, nthreads);
+    return;
+  }
+  const int n_el = (int)(left < TS ? left : TS) * D;
+  for (int e = threadIdx.x; e < TS * D; e += nthreads) {
+    const int s = magic ? (int)__umulhi((uint32_t)e, magic) : e, d = e - s * D;
+    float v = 0.0f;
+    if (e < n_el) {
+      const int64_t i = tile_start + s, sl = i / a.c_block;
+      const int64_t st = a.first_sample + sl * a.slice_stride + (i - sl * a.c_block);
+      v = normal_at(a.seed, (uint64_t)st * (uint64_t)D + (uint64_t)d);
+    }
+    U[d * TS + s] = v;
+  }
+}
+__device__ __forceinline__ void tile_noise_flow(const FlowArgsT<double>&, double*, int, uint32_t, int, int64_t, int) {}
 
 template <class R>
 __device__ __forceinline__ void tile_store(R* __restrict__ g, const R* U, int D, uint32_t magic, int TS,
@@ -420,7 +479,8 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
     const int64_t i = tile_start + SPL * threadIdx.x;
     __syncthreads();                       // previous tile's stores are done with U/O
     if (TO_BASE && !PRECISE && a.fd2) tile_load_fd<R>(a, U, DD, dmagic, TS, tile_start);
-    else tile_load<R>(a.in, U, DD, dmagic, TS, tile_start, a.B);
+    else if (a.in) tile_load<R>(a.in, U, DD, dmagic, TS, tile_start, a.B);
+    else tile_noise_flow(a, U, DD, dmagic, TS, tile_start, TILE);
     const T c = load_cond<T>(a, tile_start, i);
     __syncthreads();
 
@@ -500,7 +560,8 @@ __global__ __launch_bounds__(1024) void flow_dpar_kernel(const FlowArgs a) {
     const int64_t tile_start = tile * TS;
     const int64_t i = tile_start + SPL * lane;
     __syncthreads();
-    tile_load_n<float>(a.in, U, D, a.div_magic, TS, tile_start, a.B, NT);
+    if (a.in) tile_load_n<float>(a.in, U, D, a.div_magic, TS, tile_start, a.B, NT);
+    else tile_noise_flow(a, U, D, a.div_magic, TS, tile_start, NT);
     const T c = load_cond<T>(a, tile_start, i);
     __syncthreads();
     T base = splat<T>(0.0f);
@@ -561,6 +622,10 @@ struct PwlArgs {
   const uint32_t* gate;      // see FlowArgsT
   uint32_t gate_epoch;
   int32_t gate_want;
+  // in == null: base noise drawn in the kernel -- sample j of slice s (of this launch) is stream sample
+  // first_sample + s * slice_stride + j of the cnf_fill_normal stream of `seed`
+  uint64_t seed;
+  int64_t first_sample, slice_stride;
 };
 
 // Every reference call site hands the flow one time broadcast to cond[B,1] (applications.py:153,226,231):
@@ -688,7 +753,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
   // Tile geometry is wave-uniform (scalar registers): the slice, the tile's first sample and how many of its
   // PWL_TS samples exist.  A lane's share is then a 32-bit offset from a scalar base address, and a full tile
   // -- every tile but the last of a slice of odd size -- takes the unmasked path.
-  struct Tile { int slice; int valid; int64_t g0; };
+  struct Tile { int slice; int valid; int64_t g0; int64_t st0; };
   auto tile_of = [&](int tile) {
     Tile t;
     t.slice = tile / a.tiles_per_slice;
@@ -698,12 +763,29 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
     const int64_t left = len - jt;
     t.valid = left >= PWL_TS ? PWL_TS : (left > 0 ? (int)left : 0);
     t.g0 = s0 + jt;
+    t.st0 = a.first_sample + (int64_t)t.slice * a.slice_stride + jt;      // (seeded calls: the tile's first stream sample)
     return t;
   };
   const uint32_t lane2 = 2u * (uint32_t)tid;             // the lane's first sample within the tile
   auto tile_points = [&](const Tile& t) {
-    const float* p = a.in + 2 * t.g0;
     f4 x = {0.f, 0.f, 0.f, 0.f};
+    if (!a.in) {             // seeded: the pair's four normals (one Philox block when the pair starts on an even sample)
+      const uint64_t e0 = (uint64_t)(t.st0 + lane2) * 2u;
+      if ((int)lane2 < t.valid) {
+        if ((e0 & 3) == 0) {
+          float z[4];
+          philox_normals4(a.seed, e0 >> 2, z);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x[q] = z[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x[q] = normal_at(a.seed, e0 + q);
+        }
+        if ((int)lane2 + 1 >= t.valid) { x[2] = 0.f; x[3] = 0.f; }
+      }
+      return x;
+    }
+    const float* p = a.in + 2 * t.g0;
     if (t.valid == PWL_TS) x = *reinterpret_cast<const f4*>(p + 2u * lane2);
     else if ((int)lane2 + 1 < t.valid) x = *reinterpret_cast<const f4*>(p + 2u * lane2);
     else if ((int)lane2 < t.valid) { x[0] = p[2u * lane2]; x[1] = p[2u * lane2 + 1]; }
@@ -774,28 +856,6 @@ struct LossArgs {
   uint64_t seed;
   int64_t first_sample;
 };
-
-// One tile of base noise straight into LDS: the tile's TS*D stream elements are
-// contiguous; a thread draws whole Philox blocks (4 normals) and scatters them.
-__device__ __forceinline__ void tile_noise(uint64_t seed, uint64_t first_element, float* U, int D, uint32_t magic,
-                                           int TS, int64_t n_valid_samples) {
-  const int n_el = (int)(n_valid_samples < TS ? n_valid_samples : TS) * D;
-  const uint64_t blk0 = first_element >> 2;
-  const int n_blk = (int)(((first_element + (uint64_t)(TS * D) - 1) >> 2) - blk0) + 1;
-  for (int q = threadIdx.x; q < n_blk; q += TILE) {
-    const uint64_t blk = blk0 + (uint64_t)q;
-    float z[4];
-    philox_normals4(seed, blk, z);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t e = (int64_t)((blk << 2) + r) - (int64_t)first_element;
-      if (e >= 0 && e < TS * D) {
-        const int s = magic ? (int)__umulhi((uint32_t)e, magic) : (int)e, d = (int)e - s * D;
-        U[d * TS + s] = e < n_el ? z[r] : 0.0f;
-      }
-    }
-  }
-}
 
 template <class T>
 __device__ __forceinline__ void copy_cols(float* dst, const float* src, int D, int TS) {
@@ -948,12 +1008,6 @@ struct LossPwlArgs {
   int64_t first_sample;
   int32_t n_sets, tiles_per_slice;
 };
-
-__device__ __forceinline__ float normal_at(uint64_t seed, uint64_t e) {     // element e of the cnf_fill_normal stream
-  float z[4];
-  philox_normals4(seed, e >> 2, z);
-  return z[e & 3];
-}
 
 template <int K, bool FAST>
 __global__ __launch_bounds__(PWL_MAX_THREADS) void loss_pwl_kernel(const LossPwlArgs a) {
@@ -1608,9 +1662,13 @@ static bool pwl_config_ok(const CnfModel* m) {
 // `detect`: the condition is per-sample in form (c_block == 1); the caller passes c_block = B here.  The
 // uniformity check is enqueued first and the table kernels run only if it finds c uniform; *gate / *gate_epoch
 // return the stamp for the MLP kernel the caller enqueues behind them (which runs only if c is NOT uniform).
+// Where a base -> data call takes its points from when `in` is null: the cnf_fill_normal stream of `seed`
+struct NoiseSrc { uint64_t seed; int64_t first_sample, slice_stride; };
+
 static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float* c, int64_t c_block,
                         float* out, float* aux, int aux_mode, int64_t B, hipStream_t stream,
-                        bool detect = false, const uint32_t** gate = nullptr, uint32_t* gate_epoch = nullptr) {
+                        bool detect = false, const uint32_t** gate = nullptr, uint32_t* gate_epoch = nullptr,
+                        const NoiseSrc* noise = nullptr) {
   if (!pwl_config_ok(m)) return CNF_ERR_UNSUPPORTED;
   const int L = m->cfg.num_layers;
   const bool precise = to_base && m->precise;
@@ -1688,7 +1746,9 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
     ps.built();
     cnf::PwlArgs a;
     a.m = model_args(m);
-    a.in = in + first * 2; a.out = out ? out + first * 2 : nullptr; a.aux = aux ? aux + first : nullptr;
+    a.in = in ? in + first * 2 : nullptr; a.out = out ? out + first * 2 : nullptr; a.aux = aux ? aux + first : nullptr;
+    a.seed = noise ? noise->seed : 0; a.slice_stride = noise ? noise->slice_stride : 0;
+    a.first_sample = noise ? noise->first_sample + s0 * noise->slice_stride : 0;
     a.tables = tables;
     a.B = (B - first) < ns * slice_len ? (B - first) : ns * slice_len;
     a.slice_len = slice_len;
@@ -1716,8 +1776,10 @@ int cnf_internal_build_tables(CnfModel* m, hipStream_t stream, const float* c, i
 }
 
 static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, int64_t c_block,
-                    float* out, float* aux, int aux_mode, int64_t B, void* stream) {
-  if (!m || !in || !c || B < 0 || c_block < 1) return CNF_ERR_INVALID;
+                    float* out, float* aux, int aux_mode, int64_t B, void* stream, const NoiseSrc* noise = nullptr) {
+  if (!m || (!in && !noise) || (in && noise) || !c || B < 0 || c_block < 1) return CNF_ERR_INVALID;
+  if (noise && (to_base || noise->first_sample < 0 || noise->slice_stride < 0)) return CNF_ERR_INVALID;
+  if (noise && c_block == 1 && B > 1 && noise->slice_stride != 1) return CNF_ERR_INVALID;      // per-sample conditions: one run of the stream
   if (!out && !aux) return CNF_ERR_INVALID;
   if (!m->params_set) return CNF_ERR_INVALID;
   if (B == 0) return CNF_OK;
@@ -1728,10 +1790,10 @@ static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, 
     // per-sample conditions: uniform in every reference call (one time broadcast to cond[B,1]).  When the launch
     // is one the table path would take as a single slice, enqueue the check + the table kernels + (below) the MLP
     // kernel, gated on the device by the check's result.
-    const int r = run_flow_pwl(m, to_base, in, c, B, out, aux, aux_mode, B, (hipStream_t)stream, true, &gate, &gate_epoch);
+    const int r = run_flow_pwl(m, to_base, in, c, B, out, aux, aux_mode, B, (hipStream_t)stream, true, &gate, &gate_epoch, noise);
     if (r != CNF_OK && r != CNF_ERR_UNSUPPORTED) return r;
   } else {
-    const int r = run_flow_pwl(m, to_base, in, c, c_block, out, aux, aux_mode, B, (hipStream_t)stream);
+    const int r = run_flow_pwl(m, to_base, in, c, c_block, out, aux, aux_mode, B, (hipStream_t)stream, false, nullptr, nullptr, noise);
     if (r != CNF_ERR_UNSUPPORTED) return r;
   }
   FlowArgs a;
@@ -1740,6 +1802,7 @@ static int run_flow(CnfModel* m, bool to_base, const float* in, const float* c, 
   a.B = B; a.c_block = c_block;
   a.gate = gate; a.gate_epoch = gate_epoch; a.gate_want = 1;     // MLP kernel: only if a difference was stamped
   a.fd2 = 0; a.fd_h = 0.f; a.fd_inv_dx = 0.f;
+  a.seed = noise ? noise->seed : 0; a.first_sample = noise ? noise->first_sample : 0; a.slice_stride = noise ? noise->slice_stride : 0;
   a.aux_mode = aux_mode;
   a.div_magic = m->div_magic;
   int spl = m->fast_math ? samples_per_lane(m, B) : 1;
@@ -1780,6 +1843,14 @@ extern "C" int cnf_sample_logprob(CnfModel* m, const float* noise, const float* 
   return run_flow(m, false, noise, c, c_block, y, logp, AUX_LOGPROB, B, stream);
 }
 
+extern "C" int cnf_sample_logprob_seeded(CnfModel* m, uint64_t seed, int64_t first_sample, int64_t slice_stride,
+                                         const float* c, int64_t c_block, float* y, float* logp, int64_t B,
+                                         void* stream) {
+  if (!y) return CNF_ERR_INVALID;
+  const NoiseSrc noise{seed, first_sample, slice_stride};
+  return run_flow(m, false, nullptr, c, c_block, y, logp, AUX_LOGPROB, B, stream, &noise);
+}
+
 extern "C" int cnf_fill_normal_threefry(uint32_t key0, uint32_t key1, uint64_t size, uint64_t first_element, int64_t n,
                                         float* out_f32, double* out_f64, void* stream) {
   if (n < 0 || (n > 0 && !out_f32 && !out_f64) || first_element + (uint64_t)n > size || size > 0x7fffffffull)
@@ -1809,6 +1880,7 @@ extern "C" int cnf_logprob_fd(CnfModel* m, const float* pts, const float* c, int
   a.div_magic = m->div_magic;
   a.gate = nullptr; a.gate_epoch = 0; a.gate_want = 0;
   a.fd2 = 2 * D; a.fd_h = 0.5f * dx; a.fd_inv_dx = 1.0f / dx;
+  a.seed = 0; a.first_sample = 0; a.slice_stride = 0;
   a.c_mode = c_block >= B ? C_SINGLE : C_GENERIC;
   int spl = m->fast_math ? samples_per_lane(m, a.B) : 1;
   if (spl == 2 && (size_t)(hdr_floats(m->cfg.num_bins) + 2 * D * TILE * 2) * sizeof(float) > 160 * 1024) spl = 1;
@@ -1991,6 +2063,7 @@ static int run_flow_f64(CnfModel* m, bool to_base, const double* in, const doubl
   a.B = B; a.c_block = c_block; a.aux_mode = aux_mode; a.div_magic = m->div_magic;
   a.gate = nullptr; a.gate_epoch = 0; a.gate_want = 0;
   a.fd2 = 0; a.fd_h = 0.0; a.fd_inv_dx = 0.0;
+  a.seed = 0; a.first_sample = 0; a.slice_stride = 0;
   if (c_block >= B) a.c_mode = C_SINGLE;
   else if (c_block == 1) a.c_mode = C_PER_SAMPLE;
   else if (c_block % TILE == 0) a.c_mode = C_TILE_UNIFORM;

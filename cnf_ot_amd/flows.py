@@ -275,6 +275,35 @@ class FlowEngine:
     return self._run(self.lib.cnf_sample_logprob, "cnf_sample_logprob", noise, cond, True, want_logp,
                      out=out, aux=logp_out)
 
+  def sample_logprob_seeded(self, seed, n_samples: int, cond, want_logp=True, first_sample: int = 0,
+                            slice_stride: Optional[int] = None, out=None, logp_out=None):
+    """cnf_sample_logprob_seeded: `sample_logprob(self.normal(seed, n_samples, first_sample), cond)` bit for bit, the
+    base noise drawn inside the flow kernel (no noise tensor; one launch).  slice_stride: stream samples between
+    the slices of `cond` (default: the slice length -- n_samples consecutive samples; 0: every slice the same draw)."""
+    seed, off = seed_to_u64(seed)
+    B = int(n_samples)
+    c, c_block = self.cond(cond, B)
+    if slice_stride is None:
+      slice_stride = min(c_block, B) if c_block > 1 else 1
+    if self._pwl_mode and B > 0:
+      self.reserve(-(-B // c_block) if c_block > 1 else 1)
+    D = self.cfg.dim
+    if out is not None:
+      self._check_out(out, (B, D), "sample_logprob_seeded out")
+    else:
+      out = torch.empty(B, D, dtype=torch.float32, device=self.device)
+    if logp_out is not None:
+      self._check_out(logp_out, (B,), "sample_logprob_seeded logp")
+    elif want_logp:
+      logp_out = torch.empty(B, dtype=torch.float32, device=self.device)
+    if B > 0:
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_sample_logprob_seeded(self._h, seed, off + int(first_sample), int(slice_stride),
+                                                       c.data_ptr(), c_block, out.data_ptr(),
+                                                       logp_out.data_ptr() if logp_out is not None else None, B,
+                                                       _stream_ptr(self.device)), "cnf_sample_logprob_seeded")
+    return out, logp_out
+
   def slice_conds(self, t) -> torch.Tensor:
     """[n_slices] float32 on the device.  Host lists are uploaded once and kept (a loss evaluation asks for the
     same few condition lists -- [0], [T], the step's time batch -- for every term, loss and gradient alike)."""
@@ -611,9 +640,18 @@ class _Apply:
       raise ValueError(f"noise must have shape {(n, eng.cfg.dim)}, got {tuple(noise.shape)}")
     return noise, shape
 
+  def _seeded(self, noise, seed) -> bool:
+    """The reference's form -- `seed=` and no explicit noise (conditional.py:376-402) -- with the build's own stream:
+    the draw happens inside the flow kernel (cnf_sample_logprob_seeded), same values as drawing first."""
+    return noise is None and seed is not None and self._m.rng == "philox"
+
   # conditional.py:323-351
   def sample(self, params, *, cond, seed=None, sample_shape=(), noise=None):
     eng = self._engine(params, cond if torch.is_tensor(cond) else None)
+    if self._seeded(noise, seed):
+      n, shape = _num_samples(sample_shape)
+      y, _ = eng.sample_logprob_seeded(seed, n, cond, want_logp=False)
+      return y.reshape(shape + (eng.cfg.dim,))
     noise, shape = self._draw(eng, cond, seed, sample_shape, noise)
     y, _ = eng.sample_logprob(noise, cond, want_logp=False)
     return y.reshape(shape + (eng.cfg.dim,))
@@ -621,6 +659,10 @@ class _Apply:
   # conditional.py:353-374
   def sample_and_log_prob(self, params, *, cond, seed=None, sample_shape=(), noise=None):
     eng = self._engine(params, cond if torch.is_tensor(cond) else None)
+    if self._seeded(noise, seed):
+      n, shape = _num_samples(sample_shape)
+      y, lp = eng.sample_logprob_seeded(seed, n, cond, want_logp=True)
+      return y.reshape(shape + (eng.cfg.dim,)), lp.reshape(shape)
     noise, shape = self._draw(eng, cond, seed, sample_shape, noise)
     y, lp = eng.sample_logprob(noise, cond, want_logp=True)
     return y.reshape(shape + (eng.cfg.dim,)), lp.reshape(shape)

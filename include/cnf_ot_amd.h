@@ -168,6 +168,19 @@ int cnf_sample_logprob(CnfModel *m, const float *noise, const float *c,
                        int64_t c_block, float *y, float *logp, int64_t B,
                        void *stream);
 
+/* Replaces: model.apply.sample / sample_and_log_prob(params, cond=, seed=, sample_shape=(B,)) as the reference
+ * calls them (conditional.py:376-402: the base draw happens INSIDE the call): the same as cnf_fill_normal +
+ * cnf_sample_logprob, bit for bit, with the noise drawn in the flow kernel -- no noise tensor in HBM (12 instead
+ * of 20 bytes per sample at dim 2) and one launch instead of two.  Sample i of the call is sample
+ *   first_sample + (i / c_block) * slice_stride + i % c_block
+ * of the cnf_fill_normal stream of `seed` (element (sample) * D + d): slice_stride = c_block (or one slice,
+ * c_block >= B) draws B consecutive samples, slice_stride = 0 gives every slice the same draw (the reused rng of
+ * applications.py:392-400).  Per-sample conditions (c_block = 1) need slice_stride = 1.  logp may be NULL. */
+int cnf_sample_logprob_seeded(CnfModel *m, uint64_t seed, int64_t first_sample,
+                              int64_t slice_stride, const float *c,
+                              int64_t c_block, float *y, float *logp, int64_t B,
+                              void *stream);
+
 /* float64 instantiation of the four functions above: the reference computes in
  * float64 (jax.config.update("jax_enable_x64", True), solvers.py:23).  Double
  * IO, double spline table and constants, ocml math, one sample per lane:

@@ -395,6 +395,44 @@ def test_entry_points_are_graph_capturable(dev):
   eng.set_pwl(1)
 
 
+@pytest.mark.parametrize("D", [2, 3, 10])
+def test_seeded_sampling_is_fill_normal_plus_sample_logprob(dev, D):
+  """cnf_sample_logprob_seeded (model.apply.sample / sample_and_log_prob(seed=), conditional.py:376-402: the base draw
+  inside the call) == cnf_fill_normal + cnf_sample_logprob bit for bit, on every kernel path: tables and MLP kernels
+  at 65 536 x 7 slices (dim 2), the small-launch MFMA kernel, the wave-per-dimension kernel (dim >= 3), per-sample
+  conditions, ragged sizes, a stream offset, and every slice reusing one draw (slice_stride = 0)."""
+  from cnf_ot_amd import FlowConfig, FlowModel, Params
+  cfg = FlowConfig(dim=D); model = FlowModel(cfg)
+  params = Params.random(cfg, 0.2 if D == 2 else 0.12, seed=70 + D, device=dev)
+  eng = model.engine(dev).load(params)
+  cases = [(7, 65536 if D == 2 else 8192, 2), (7, 65536 if D == 2 else 8192, 0), (1, 65536, 1), (5, 1001, 1), (3, 4096, 1)]
+  for S, Bs, mode in cases:
+    if D != 2 and mode == 0:
+      continue
+    eng.set_pwl(mode)
+    t = torch.linspace(0.05, 0.95, S, device=dev)
+    for first in (0, 12345):
+      noise = eng.normal(99, S * Bs, first_sample=first)
+      y0, lp0 = eng.sample_logprob(noise, t)
+      path = eng.last_path()
+      y1, lp1 = eng.sample_logprob_seeded(99, S * Bs, t, first_sample=first)
+      assert eng.last_path() == path
+      assert torch.equal(y0, y1) and torch.equal(lp0, lp1), (D, S, Bs, mode, first, path)
+    # every slice the same draw (the reused rng of applications.py:392-400)
+    one = eng.normal(5, Bs)
+    y0, lp0 = eng.sample_logprob(one.repeat(S, 1), t)
+    y1, lp1 = eng.sample_logprob_seeded(5, S * Bs, t, slice_stride=0)
+    assert torch.equal(y0, y1) and torch.equal(lp0, lp1), (D, S, Bs, mode, "stride 0")
+  eng.set_pwl(1)
+  # per-sample conditions cond[B, 1] (the reference's literal form), uniform and not: through model.apply
+  B = 65536 if D == 2 else 4096
+  for cond in (torch.full((B, 1), 0.4, device=dev), torch.linspace(0.0, 1.0, B, device=dev)[:, None].contiguous()):
+    ya, lpa = model.apply.sample_and_log_prob(params, cond=cond, seed=31, sample_shape=(B,))
+    yb, lpb = model.apply.sample_and_log_prob(params, cond=cond, noise=eng.normal(31, B), sample_shape=(B,))
+    assert torch.equal(ya, yb) and torch.equal(lpa, lpb)
+    assert torch.equal(model.apply.sample(params, cond=cond, seed=31, sample_shape=(B,)), ya)
+
+
 def test_graph_replay_survives_a_larger_reservation(dev):
   """A HIP graph captured on the table path has the workspace address baked into its kernel arguments.  Growing the
   stream's reservation afterwards (an eager call with more slices) must not free that block: the replay that follows
