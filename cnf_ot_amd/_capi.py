@@ -88,6 +88,13 @@ SYMBOLS = {
                                       ctypes.c_float, _P, _P, _P, _P]),
   "cnf_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                    ctypes.c_float, _I64, _P]),
+  "cnf_step_begin": (ctypes.c_int, [_P, _P]),
+  "cnf_fill_normal_dev": (ctypes.c_int, [_P, _U64, _I64, _P, _P]),
+  "cnf_fill_uniform_dev": (ctypes.c_int, [_P, _U64, _I64, ctypes.c_float, _P, _P]),
+  "cnf_mixture_source_dev": (ctypes.c_int, [_P, _U64, _I64, _P, _P, _P, _P]),
+  "cnf_adam_step_dev": (ctypes.c_int, [_P, _P, _P, _P, _I64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                       ctypes.c_float, _P, _P]),
+  "cnf_weighted_sum": (ctypes.c_int, [_P, _P, _I64, _P, _P]),
   "cnf_strerror": (ctypes.c_char_p, [ctypes.c_int]),
   "cnf_build_arch": (ctypes.c_char_p, []),
   "cnf_config_supported": (ctypes.c_int, [_CFG]),

@@ -27,7 +27,7 @@ import torch
 
 from . import _capi
 from .distributed import Shard, all_reduce_sums, current_shard, shard_range
-from .flows import seed_to_u64
+from .flows import DeviceRng, _stream_ptr, seed_to_u64
 
 # Cholesky factor L (lower: A = L L^T, applied as z @ L like oracle/losses.py) of the Gaussian source's covariance A = [[5, 1], [1, .5]]
 # (applications.py:28-32), computed once: torch.linalg.cholesky of a 2 x 2 CPU tensor costs ~20 ms PER CALL on a
@@ -50,9 +50,29 @@ def host_rng(rng, stream: int) -> np.random.Generator:
   return np.random.default_rng([seed & 0xFFFFFFFF, seed >> 32, off, stream])
 
 
-def draw_t_batch(rng, t_batch_size: int, scale: float = 1.0) -> np.ndarray:
-  """jax.random.uniform(rng, (t_batch_size,)) * T (applications.py:392,414,434)."""
+def draw_t_batch(rng, t_batch_size: int, scale: float = 1.0):
+  """jax.random.uniform(rng, (t_batch_size,)) * T (applications.py:392,414,434): a host array, or -- for a DeviceRng --
+  a device tensor drawn by cnf_fill_uniform_dev from the key in device memory."""
+  if isinstance(rng, DeviceRng):
+    out = torch.empty(t_batch_size, dtype=torch.float32, device=rng.device)
+    with torch.cuda.device(rng.device):
+      _capi.check(_capi.lib().cnf_fill_uniform_dev(rng.ptr, 0, t_batch_size, float(scale), out.data_ptr(),
+                                                   _stream_ptr(rng.device)), "cnf_fill_uniform_dev")
+    return out
   return (host_rng(rng, 1).uniform(0.0, 1.0, size=t_batch_size) * scale).astype(np.float32)
+
+
+def _conds(t):
+  """time-slice conditions as the term functions pass them on: a device tensor stays one, the rest a float32 array"""
+  return t.reshape(-1) if torch.is_tensor(t) else np.atleast_1d(np.asarray(t, dtype=np.float32)).reshape(-1)
+
+
+def _n_conds(t) -> int:
+  return int(t.numel()) if torch.is_tensor(t) else int(np.atleast_1d(t).size)
+
+
+def _cat_conds(parts):
+  return torch.cat(list(parts)) if torch.is_tensor(parts[0]) else np.concatenate(list(parts))
 
 
 def draw_components(rng, n: int) -> np.ndarray:
@@ -72,27 +92,48 @@ class _Ctx:
     self.grad = grad
     self._noise = {}
     self._passes = []       # base -> data backward passes waiting for ONE launch (defer_pass_vjp)
+    # the terms' per-slice sums land side by side in one buffer: `reduce` needs no concatenation kernel
+    self._sumbuf = torch.empty(256, dtype=torch.float64, device=self.be.device) if hasattr(self.be, "device") and \
+        getattr(self.be.device, "type", "cpu") == "cuda" else None
+    self._sumpos = 0
+
+  def new_sums(self, n: int):
+    if self._sumbuf is None or self._sumpos + n > self._sumbuf.numel():
+      return None
+    v = self._sumbuf[self._sumpos:self._sumpos + n]
+    self._sumpos += n
+    return v
 
   def noise(self, n_global: int) -> torch.Tensor:
     """This rank's rows of the first n_global samples of the seed's stream."""
     if n_global not in self._noise:
       start, count = shard_range(n_global, self.shard)
+      if self.shard.world == 1:      # one rank: a smaller draw is the first rows of a larger one already made
+        for n_have, (z, _, _) in self._noise.items():
+          if isinstance(n_have, int) and n_have >= n_global:
+            self._noise[n_global] = (z[:n_global], 0, n_global)
+            return self._noise[n_global]
       self._noise[n_global] = (self.be.normal(self.rng, count, first_sample=start), start, count)
     return self._noise[n_global]
 
   def terms(self, spec, pts, t, B_local, coef, shared=True):
     """per-slice sums of one term; `coef` = d(loss)/d(sum) (the same for every slice)."""
-    t = np.atleast_1d(np.asarray(t, dtype=np.float32))
+    t = _conds(t)
+    kw = {}
+    if self._sumbuf is not None:
+      s = self.new_sums(_n_conds(t))
+      if s is not None:
+        kw["sums"] = s
     if self.grad is not None:
-      return self.be.loss_terms_grad(spec, pts, t, B_local, shared, coef, self.grad)
-    return self.be.loss_terms(spec, pts, t, B_local, shared)
+      return self.be.loss_terms_grad(spec, pts, t, B_local, shared, coef, self.grad, **kw)
+    return self.be.loss_terms(spec, pts, t, B_local, shared, **kw)
 
   def defer_pass_vjp(self, z, conds, count: int, ybar, ldbar):
     """Queue the backward of a base -> data pass (points z [S * count, D], one condition per slice of `count`
     points) instead of launching it: the passes of a loss's terms go out as ONE cnf_pass_vjp launch in `reduce`.
     A rank's share of a term is often too small to fill the GPU on its own (config 4: 512 and 1 536 waves for 2 048
     wave slots, each wave one tile -- two launches took two tile times, the merged one takes one)."""
-    self._passes.append((z, np.asarray(conds, dtype=np.float32).reshape(-1), int(count), ybar, ldbar))
+    self._passes.append((z, _conds(conds), int(count), ybar, ldbar))
 
   def flush_passes(self):
     passes, self._passes = self._passes, []
@@ -106,7 +147,15 @@ class _Ctx:
     g = 0
     for _, _, count, _, _ in passes:
       g = int(np.gcd(g, count))
-    conds = np.concatenate([np.repeat(c, count // g) for _, c, count, _, _ in passes])
+    dev = any(torch.is_tensor(c) for _, c, _, _, _ in passes)
+    rep = []
+    for _, c, count, _, _ in passes:
+      if dev:
+        c = c if torch.is_tensor(c) else torch.from_numpy(np.ascontiguousarray(c)).to(be.device)
+        rep.append(c.repeat_interleave(count // g))
+      else:
+        rep.append(np.repeat(c, count // g))
+    conds = _cat_conds(rep)
     z = torch.cat([p[0] for p in passes])
     ybar = torch.cat([p[3] if p[3] is not None else torch.zeros_like(p[0]) for p in passes])
     ldbar = None
@@ -119,6 +168,13 @@ class _Ctx:
     self.flush_passes()
     parts = [s.reshape(-1).to(torch.float64) for s in sums]
     n = sum(p.numel() for p in parts)
+    if self._sumbuf is not None and len(parts) > 1:      # side by side in the sums buffer already: no concatenation
+      ptr, ok = parts[0].data_ptr(), parts[0].data_ptr() == self._sumbuf.data_ptr()
+      for q in parts:
+        ok = ok and q.data_ptr() == ptr
+        ptr += 8 * q.numel()
+      if ok:
+        parts = [self._sumbuf[:n]]
     if self.grad is not None and self.shard.world > 1:
       flat = all_reduce_sums(torch.cat(parts + [self.grad.to(torch.float64)]), self.shard)
       self.grad.copy_(flat[n:].to(torch.float32))
@@ -136,6 +192,12 @@ class _Ctx:
         _WEIGHTS.clear()
       w = _WEIGHTS[key] = torch.tensor(np.concatenate([np.full(n, c, dtype=np.float64) for c, n in key[0]]),
                                        dtype=torch.float64, device=flat.device)
+    if flat.is_cuda:       # one block, fixed order, no BLAS call (and nothing a stream capture could not record)
+      out = torch.empty(1, dtype=torch.float64, device=flat.device)
+      with torch.cuda.device(flat.device):
+        _capi.check(_capi.lib().cnf_weighted_sum(flat.data_ptr(), w.data_ptr(), flat.numel(), out.data_ptr(),
+                                                 _stream_ptr(flat.device)), "cnf_weighted_sum")
+      return out[0]
     return torch.dot(flat, w)
 
 
@@ -148,6 +210,12 @@ def _source_samples(ctx, z, start, count, n_global, source):
   if source == "mixture":      # applications.py:34-71 (live code)
     if z.shape[1] != 2:
       raise ValueError("the mixture source of kl_loss_fn is 2-D (applications.py:40-67)")
+    if isinstance(ctx.rng, DeviceRng):
+      out = torch.empty_like(z)
+      with torch.cuda.device(z.device):
+        _capi.check(_capi.lib().cnf_mixture_source_dev(ctx.rng.ptr, start, count, z.data_ptr(), out.data_ptr(), None,
+                                                       _stream_ptr(z.device)), "cnf_mixture_source_dev")
+      return out
     comp = draw_components(ctx.rng, n_global)[start:start + count]
     centers = torch.from_numpy(MIXTURE_CENTERS[comp]).to(z.device)
     return z + centers
@@ -194,10 +262,10 @@ def _neg_logprob_tables(ctx, samples, cond, coef):
 def _kinetic_tables(ctx, z, conds, count, dt, coef):
   """per-slice sums of |(r2 - r1) / dt|^2 with r1, r2 the same draw pushed to t -+ dt/2 (applications.py:220-242)."""
   be = ctx.be
-  th = np.asarray(conds, dtype=np.float32).reshape(-1)
-  S = th.size
+  th = _conds(conds)
+  S = _n_conds(th)
   half = np.float32(0.5 * dt)
-  c2 = be.slice_conds(np.concatenate([th - half, th + half]))
+  c2 = be.slice_conds(_cat_conds([th - half, th + half]))
   z2 = z.repeat(2 * S, 1)
   r, _ = be.forward_logdet(z2, c2, want_logdet=False)
   sums, rbar, _ = be.term_residual(_capi.TERM_KINETIC, r, None, count, p0=dt, loss_coef=coef)
@@ -208,8 +276,8 @@ def _kinetic_tables(ctx, z, conds, count, dt, coef):
 def _potential_tables(ctx, z, conds, count, subtype, a, coef):
   """per-slice sums of the potential at the samples pushed to the slices' times (applications.py:176-205)."""
   be = ctx.be
-  th = np.asarray(conds, dtype=np.float32).reshape(-1)
-  S = th.size
+  th = _conds(conds)
+  S = _n_conds(th)
   c = be.slice_conds(th)
   zr = z.repeat(S, 1) if S > 1 else z
   r, _ = be.forward_logdet(zr, c, want_logdet=False)
@@ -247,15 +315,15 @@ def _potential_sum(ctx, a, subtype, conds, batch_size, coef):
   if subtype not in _capi.POTENTIALS:
     raise ValueError(f"unknown potential {subtype!r}")
   z, _, count = ctx.noise(batch_size)
-  if _use_table_backward(ctx, z.shape[1], count, len(conds)):
+  if _use_table_backward(ctx, z.shape[1], count, _n_conds(conds)):
     return _potential_tables(ctx, z, conds, count, subtype, a, coef)
   return ctx.terms(_spec(_capi.TERM_POTENTIAL, subtype=_capi.POTENTIALS[subtype], a=a), z, conds, count, coef)
 
 
 def _kinetic_sum(ctx, dt, conds, batch_size, coef):
   z, _, count = ctx.noise(batch_size)
-  if _use_table_backward(ctx, z.shape[1], count, len(np.atleast_1d(conds)), passes=2):
-    return _kinetic_tables(ctx, z, np.atleast_1d(conds), count, dt, coef)
+  if _use_table_backward(ctx, z.shape[1], count, _n_conds(conds), passes=2):
+    return _kinetic_tables(ctx, z, conds, count, dt, coef)
   return ctx.terms(_spec(_capi.TERM_KINETIC, dt=dt), z, conds, count, coef)
 
 
@@ -280,14 +348,14 @@ def _score_terms_unfused(ctx, conds, batch_size, dt, dx, coef_score, loss_coef, 
   the parameter gradient -- the reverse sweep written out by hand: no autograd graph, a dozen host calls."""
   be = ctx.be
   z, _, count = ctx.noise(batch_size)
-  S = len(conds)
+  S = _n_conds(conds)
   n = S * count
   # conditions per SLICE (the engine broadcasts a slice's value over its `count` samples): 3 S floats, built on the
   # host and uploaded once per distinct time batch -- not per-sample tensors assembled by a chain of small kernels
-  th = np.asarray(conds, dtype=np.float32).reshape(-1)
+  th = _conds(conds)
   half = np.float32(0.5 * dt)
   tt = be.slice_conds(th)
-  c3 = be.slice_conds(np.concatenate([th - half, th + half, th]))
+  c3 = be.slice_conds(_cat_conds([th - half, th + half, th]))
   z3 = z.repeat(3 * S, 1)                                     # the same draw for every slice and condition
   want = ctx.grad is not None
   r, _ = be.forward_logdet(z3, c3, want_logdet=False)
@@ -295,7 +363,7 @@ def _score_terms_unfused(ctx, conds, batch_size, dt, dx, coef_score, loss_coef, 
     # value AND backward of the score term in one launch: the kernel that differentiates the 2 D evaluation points
     # forms the score from its own forward passes (no separate forward launch over them)
     sums, rbar = be.score_fd_vjp(r, tt, count, dt, dx, coef_score, drift, a, loss_coef, ctx.grad)
-    ctx.defer_pass_vjp(z3, np.concatenate([th - half, th + half, th]), count, rbar, None)
+    ctx.defer_pass_vjp(z3, _cat_conds([th - half, th + half, th]), count, rbar, None)
     return sums
   r3 = r[2 * n:]
   score = be.logprob_fd(r3, tt, dx)
@@ -303,7 +371,7 @@ def _score_terms_unfused(ctx, conds, batch_size, dt, dx, coef_score, loss_coef, 
   if want:
     r3bar = be.logprob_fd_vjp(r3, tt, dx, sbar, ctx.grad)     # adjoint of r3 through the score; + parameter gradient
     rbar[2 * n:] += r3bar
-    ctx.defer_pass_vjp(z3, np.concatenate([th - half, th + half, th]), count, rbar, None)
+    ctx.defer_pass_vjp(z3, _cat_conds([th - half, th + half, th]), count, rbar, None)
   return sums
 
 
@@ -331,7 +399,7 @@ def _use_unfused(ctx, dim):
 def _kinetic_score_sum(ctx, beta, dt, dx, conds, batch_size, coef):
   z, _, count = ctx.noise(batch_size)
   if _use_unfused(ctx, z.shape[1]):
-    return _score_terms_unfused(ctx, np.atleast_1d(conds), batch_size, dt, dx, 1.0 / beta, coef)
+    return _score_terms_unfused(ctx, conds, batch_size, dt, dx, 1.0 / beta, coef)
   return ctx.terms(_spec(_capi.TERM_KINETIC_SCORE, dt=dt, dx=dx, coef=1.0 / beta), z, conds, count, coef)
 
 
@@ -347,7 +415,7 @@ def _flow_matching_sum(ctx, dim, a, sigma, subtype, conds, batch_size, coef):
                      "use subtype='ou' for the documented drift -a*r in other dimensions")
   z, _, count = ctx.noise(batch_size)
   if _use_unfused(ctx, dim) and subtype in ("ou", "lorenz"):
-    return _score_terms_unfused(ctx, np.atleast_1d(conds), batch_size, 0.01, 0.01, sigma, coef, _capi.DRIFTS[subtype], a)
+    return _score_terms_unfused(ctx, conds, batch_size, 0.01, 0.01, sigma, coef, _capi.DRIFTS[subtype], a)
   # dt and dx are overridden to 0.01 inside the reference function (:286,301)
   return ctx.terms(_spec(_capi.TERM_FLOW_MATCHING, subtype=_capi.DRIFTS[subtype], dt=0.01, dx=0.01,
                          coef=sigma, a=a), z, conds, count, coef)

@@ -1138,8 +1138,11 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void loss_pwl_kernel(const LossPwl
 // Base noise: Philox4x32-10 + Box-Muller; one counter block (4 normals) per
 // thread.  Element e of the stream uses block e>>2, word pair (e&3)>>1.
 // ---------------------------------------------------------------------------
+// seed_dev (optional): the key is read from device memory -- state[1] of a training step's device-side state
+// (cnf_step_begin) -- so that a captured step draws new noise on every replay
 __global__ void fill_normal_kernel(uint64_t seed, uint64_t first_element, int64_t n,
-                                   float* __restrict__ out) {
+                                   float* __restrict__ out, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed = seed_dev[1];
   const uint64_t first_blk = first_element >> 2;
   const uint64_t last_blk = (first_element + (uint64_t)n - 1) >> 2;
   for (uint64_t blk = first_blk + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; blk <= last_blk;
@@ -1463,7 +1466,11 @@ extern "C" int cnf_model_set_params(CnfModel* m, const float* params, void* stre
                        (hipStream_t)stream, params, m->prep, K, m->cfg.hidden_size, m->cfg.dim, m->cfg.num_layers,
                        m->cfg.mlp_num_layers, m->per_layer);
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
-  if (hipEventRecord(m->prep_event, (hipStream_t)stream) != hipSuccess) return CNF_ERR_HIP;
+  // (inside a stream capture the record would become a graph node and leave the event unusable outside the graph:
+  //  a captured step is ordered by its own stream)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+  if (cap == hipStreamCaptureStatusNone && hipEventRecord(m->prep_event, (hipStream_t)stream) != hipSuccess) return CNF_ERR_HIP;
   m->prep_stream = stream;
   m->params_set = 1;
   return CNF_OK;
@@ -1900,7 +1907,86 @@ extern "C" int cnf_fill_normal(uint64_t seed, uint64_t first_element, int64_t n,
   uint64_t grid = (n_blk + 255) / 256;
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, seed,
-                     first_element, n, out);
+                     first_element, n, out, (const uint64_t*)nullptr);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+// ---- the random inputs of a training step drawn from a key in DEVICE memory ---------------------------------------
+// state: uint64[2] on the device = { step count, key }.  The caller writes the key (one 8-byte copy) before a step;
+// every draw below reads it on the device, so the whole step -- draws, loss, gradient, Adam -- can be captured into
+// a HIP graph once and replayed with a new key each time.  Streams of one key: the normal stream of
+// cnf_fill_normal (Philox counter words 2, 3 = 0, 0), uniforms (word 2 = 1) and 3-bit integers (word 2 = 2).
+namespace cnf {
+__global__ void step_begin_kernel(uint64_t* state) { if (threadIdx.x == 0 && blockIdx.x == 0) state[0] += 1; }
+
+// out[i] = scale * u, u = 24-bit uniform in [0, 1) from word (first + i) & 3 of block (first + i) >> 2 of stream 1
+__global__ void fill_uniform_kernel(const uint64_t* __restrict__ state, uint64_t first, int64_t n, float scale,
+                                    float* __restrict__ out) {
+  const uint64_t key = state[1];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t e = first + (uint64_t)i;
+    uint32_t u[4];
+    philox4x32((uint32_t)(e >> 2), (uint32_t)(e >> 34), 1u, 0u, (uint32_t)key, (uint32_t)(key >> 32), u);
+    out[i] = scale * ((float)(u[e & 3] >> 8) * (1.0f / 16777216.0f));
+  }
+}
+
+// The 8-mode mixture source of kl_loss_fn (applications.py:34-71) for n samples of dim 2: out[i] = z[i] + centre of
+// component (first_sample + i), the component = the top 3 bits of word e & 3 of block e >> 2 of stream 2
+__global__ void mixture_source_kernel(const uint64_t* __restrict__ state, uint64_t first_sample, int64_t n,
+                                      const float* __restrict__ z, float* __restrict__ out, int32_t* __restrict__ comp_out) {
+  constexpr float R = 5.0f;
+  const float cx[8] = {0.0f, 1.0f, 0.0f, -1.0f, 0.6f, 0.6f, -0.6f, -0.6f};
+  const float cy[8] = {1.0f, 0.0f, -1.0f, 0.0f, 0.8f, -0.8f, -0.8f, 0.8f};
+  const uint64_t key = state[1];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t e = first_sample + (uint64_t)i;
+    uint32_t u[4];
+    philox4x32((uint32_t)(e >> 2), (uint32_t)(e >> 34), 2u, 0u, (uint32_t)key, (uint32_t)(key >> 32), u);
+    const int k = (int)(u[e & 3] >> 29);
+    float mx = 0.0f, my = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mx = k == j ? cx[j] : mx; my = k == j ? cy[j] : my; }
+    if (out) { out[2 * i] = z[2 * i] + R * mx; out[2 * i + 1] = z[2 * i + 1] + R * my; }
+    if (comp_out) comp_out[i] = k;
+  }
+}
+}  // namespace cnf
+
+extern "C" int cnf_step_begin(uint64_t* state, void* stream) {
+  if (!state) return CNF_ERR_INVALID;
+  hipLaunchKernelGGL(cnf::step_begin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+extern "C" int cnf_fill_normal_dev(const uint64_t* state, uint64_t first_element, int64_t n, float* out, void* stream) {
+  if (!state || n < 0 || (n > 0 && !out)) return CNF_ERR_INVALID;
+  if (n == 0) return CNF_OK;
+  const uint64_t n_blk = ((first_element + (uint64_t)n - 1) >> 2) - (first_element >> 2) + 1;
+  uint64_t grid = (n_blk + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (uint64_t)0,
+                     first_element, n, out, state);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+extern "C" int cnf_fill_uniform_dev(const uint64_t* state, uint64_t first, int64_t n, float scale, float* out, void* stream) {
+  if (!state || n < 0 || (n > 0 && !out)) return CNF_ERR_INVALID;
+  if (n == 0) return CNF_OK;
+  int64_t grid = (n + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(cnf::fill_uniform_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, state, first, n, scale, out);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+extern "C" int cnf_mixture_source_dev(const uint64_t* state, uint64_t first_sample, int64_t n, const float* z, float* out,
+                                      int32_t* comp, void* stream) {
+  if (!state || n < 0 || (n > 0 && !out && !comp) || (out && !z)) return CNF_ERR_INVALID;
+  if (n == 0) return CNF_OK;
+  int64_t grid = (n + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(cnf::mixture_source_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, state, first_sample,
+                     n, z, out, comp);
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 

@@ -1170,6 +1170,37 @@ __global__ void adam_kernel(float* __restrict__ params, const float* __restrict_
   params[i] -= lr * (m / bc1) / (sqrtf(v / bc2) + eps);
 }
 
+// The same update with the step count read from device memory (state[0] of cnf_step_begin, already incremented for
+// this step): the bias corrections cannot be kernel arguments of a step that is captured once and replayed
+__global__ void adam_dev_kernel(float* __restrict__ params, const float* __restrict__ grad, float* __restrict__ mu,
+                                float* __restrict__ nu, int64_t n, float lr, float b1, float b2, float eps,
+                                const uint64_t* __restrict__ state) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float step = (float)state[0];
+  const float bc1 = 1.0f - powf(b1, step), bc2 = 1.0f - powf(b2, step);
+  const float g = grad[i];
+  const float m = b1 * mu[i] + (1.0f - b1) * g;
+  const float v = b2 * nu[i] + (1.0f - b2) * g * g;
+  mu[i] = m; nu[i] = v;
+  params[i] -= lr * (m / bc1) / (sqrtf(v / bc2) + eps);
+}
+
+// out[0] = sum_i v[i] w[i]: the composite loss from the terms' per-slice sums and their coefficients, in a fixed order
+__global__ __launch_bounds__(256) void weighted_sum_kernel(const double* __restrict__ v, const double* __restrict__ w,
+                                                           int64_t n, double* __restrict__ out) {
+  __shared__ double part[256];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) acc += v[i] * w[i];
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = part[0];
+}
+
 // ---------------------------------------------------------------------------
 // Epilogues of the UNFUSED loss terms (dim >= applications.UNFUSED_SCORE_MIN_DIM: the flow passes are separate,
 // chip-filling launches; these turn their outputs into per-slice sums and, for value_and_grad, into the adjoints
@@ -1544,6 +1575,21 @@ extern "C" int cnf_adam_step(float* params, const float* grad, float* mu, float*
   const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grad,
                      mu, nu, n, lr, b1, b2, eps, bc1, bc2);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+extern "C" int cnf_adam_step_dev(float* params, const float* grad, float* mu, float* nu, int64_t n, float lr, float b1,
+                                 float b2, float eps, const uint64_t* state, void* stream) {
+  if (!params || !grad || !mu || !nu || !state || n < 0) return CNF_ERR_INVALID;
+  if (n == 0) return CNF_OK;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grad,
+                     mu, nu, n, lr, b1, b2, eps, state);
+  return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+extern "C" int cnf_weighted_sum(const double* v, const double* w, int64_t n, double* out, void* stream) {
+  if (!v || !w || !out || n < 0) return CNF_ERR_INVALID;
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, v, w, n, out);
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 

@@ -61,6 +61,40 @@ def seed_to_u64(seed) -> Tuple[int, int]:
   return int(seed) & _MASK64, int(offset)
 
 
+class DeviceRng:
+  """A training step's random key in DEVICE memory: `state` = int64[2] = [step count, key] (include/cnf_ot_amd.h,
+  "a training step as one device-side program").  Pass it wherever the loss functions take `rng`: base noise, the time
+  batch and the mixture components are then drawn by kernels that read the key on the device, so a step can be
+  captured into a HIP graph once and replayed with a new key -- `set_key` is one 8-byte asynchronous copy."""
+
+  SLOTS = 32       # keys in flight: the host may run this many steps ahead of the GPU before it waits for a copy
+
+  def __init__(self, device):
+    self.device = torch.device(device)
+    self.state = torch.zeros(2, dtype=torch.int64, device=self.device)
+    self._pin = torch.zeros(self.SLOTS, dtype=torch.int64).pin_memory()
+    self._done = [None] * self.SLOTS          # event behind each slot's last copy
+    self._n = 0
+
+  def set_key(self, rng) -> "DeviceRng":
+    seed, off = seed_to_u64(rng)
+    seed = (seed + 0x9E3779B97F4A7C15 * off) & _MASK64
+    k = self._n % self.SLOTS
+    self._n += 1
+    if self._done[k] is not None:
+      self._done[k].synchronize()             # (the asynchronous copy reads the pinned slot when it EXECUTES)
+    else:
+      self._done[k] = torch.cuda.Event()
+    self._pin[k] = seed - (1 << 64) if seed >= (1 << 63) else seed
+    self.state[1:2].copy_(self._pin[k:k + 1], non_blocking=True)
+    self._done[k].record(torch.cuda.current_stream(self.device))
+    return self
+
+  @property
+  def ptr(self) -> int:
+    return self.state.data_ptr()
+
+
 class FlowEngine:
   """One CnfModel handle (C ABI) on one GPU.  Explicit, allocation-light API
   used by the loss code, the evaluators and bench.py."""
@@ -319,7 +353,7 @@ class FlowEngine:
       d = cache[key] = torch.from_numpy(a.copy()).to(self.device)
     return d
 
-  def loss_terms(self, spec: "_capi.CnfLossSpec", pts, t, B: int, shared: bool) -> torch.Tensor:
+  def loss_terms(self, spec: "_capi.CnfLossSpec", pts, t, B: int, shared: bool, sums=None) -> torch.Tensor:
     """cnf_loss_terms: per-slice SUMS (float64 [n_slices]) of one Monte-Carlo
     loss term.  pts: base noise (or data points) [B, D] if `shared` else
     [n_slices*B, D]; t: [n_slices]."""
@@ -329,7 +363,8 @@ class FlowEngine:
     need = B if shared else n_slices * B
     if pts.shape[0] != need:
       raise ValueError(f"loss_terms: pts has {pts.shape[0]} rows, expected {need}")
-    sums = torch.empty(n_slices, dtype=torch.float64, device=self.device)
+    if sums is None:
+      sums = torch.empty(n_slices, dtype=torch.float64, device=self.device)
     if self._pwl_mode and n_slices > 0:
       self.reserve(n_slices, _sets_of(spec))
     if n_slices > 0:
@@ -354,7 +389,7 @@ class FlowEngine:
                                                    _stream_ptr(self.device)), "cnf_loss_terms_seeded")
     return sums
 
-  def loss_terms_grad(self, spec, pts, t, B: int, shared: bool, scale: float, grad: torch.Tensor) -> torch.Tensor:
+  def loss_terms_grad(self, spec, pts, t, B: int, shared: bool, scale: float, grad: torch.Tensor, sums=None) -> torch.Tensor:
     """cnf_loss_terms_grad: like `loss_terms`, and accumulates
     scale * d(sum of the term)/d(params) into `grad` (flat float32 [n_params])."""
     if self._flat is None:
@@ -370,7 +405,8 @@ class FlowEngine:
     if pts.shape[0] != need:
       raise ValueError(f"loss_terms_grad: pts has {pts.shape[0]} rows, expected {need}")
     self._check_out(grad, (self.cfg.param_count(),), "grad")
-    sums = torch.empty(n_slices, dtype=torch.float64, device=self.device)
+    if sums is None:
+      sums = torch.empty(n_slices, dtype=torch.float64, device=self.device)
     if n_slices > 0:
       with torch.cuda.device(self.device):
         _capi.check(self.lib.cnf_loss_terms_grad(self._h, _capi.ctypes.byref(spec), pts.data_ptr(),
@@ -570,9 +606,17 @@ class FlowEngine:
     return out
 
   def normal(self, seed, n_samples: int, first_sample: int = 0) -> torch.Tensor:
-    """Base noise [n_samples, D]: Philox stream element (first_sample+i)*D+d."""
-    seed, off = seed_to_u64(seed)
+    """Base noise [n_samples, D]: Philox stream element (first_sample+i)*D+d.  `seed`: an integer / key array, or a
+    DeviceRng (the key is read on the device: cnf_fill_normal_dev)."""
     D = self.cfg.dim
+    if isinstance(seed, DeviceRng):
+      out = torch.empty(n_samples, D, dtype=torch.float32, device=self.device)
+      if n_samples > 0:
+        with torch.cuda.device(self.device):
+          _capi.check(self.lib.cnf_fill_normal_dev(seed.ptr, first_sample * D, n_samples * D, out.data_ptr(),
+                                                   _stream_ptr(self.device)), "cnf_fill_normal_dev")
+      return out
+    seed, off = seed_to_u64(seed)
     out = torch.empty(n_samples, D, dtype=torch.float32, device=self.device)
     if n_samples > 0:
       with torch.cuda.device(self.device):

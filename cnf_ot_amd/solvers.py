@@ -12,7 +12,7 @@ from typing import Any, Callable, Dict, Tuple
 import torch
 
 from . import _capi, applications
-from .flows import RQSFlow, FlowModel, _stream_ptr, mark_updated
+from .flows import DeviceRng, RQSFlow, FlowModel, _stream_ptr, mark_updated
 from .params import Params
 
 # config/mfc.yaml:6-40 (the checked-in defaults)
@@ -84,25 +84,88 @@ class Adam:
   def init(self, params: Params) -> AdamState:
     return AdamState(0, torch.zeros_like(params.flat), torch.zeros_like(params.flat))
 
-  def apply(self, params: Params, grads: Params, state: AdamState) -> AdamState:
+  def apply(self, params: Params, grads: Params, state: AdamState, step_state: torch.Tensor = None) -> AdamState:
     """optimizer.update + optax.apply_updates (solvers.py:95-96), in place on
-    params.flat (one kernel: cnf_adam_step)."""
+    params.flat (one kernel: cnf_adam_step).  step_state: a DeviceRng's `state` -- the step count is then read on the
+    device (cnf_adam_step_dev; cnf_step_begin has already counted this step), as a captured step needs it."""
     lib = _capi.lib()
     state.step += 1
     dev = params.flat.device
     with torch.cuda.device(dev):
-      _capi.check(lib.cnf_adam_step(params.flat.data_ptr(), grads.flat.data_ptr(), state.mu.data_ptr(),
-                                    state.nu.data_ptr(), params.flat.numel(), self.lr, self.b1, self.b2, self.eps,
-                                    state.step, _stream_ptr(dev)), "cnf_adam_step")
+      if step_state is not None:
+        _capi.check(lib.cnf_adam_step_dev(params.flat.data_ptr(), grads.flat.data_ptr(), state.mu.data_ptr(),
+                                          state.nu.data_ptr(), params.flat.numel(), self.lr, self.b1, self.b2, self.eps,
+                                          step_state.data_ptr(), _stream_ptr(dev)), "cnf_adam_step_dev")
+      else:
+        _capi.check(lib.cnf_adam_step(params.flat.data_ptr(), grads.flat.data_ptr(), state.mu.data_ptr(),
+                                      state.nu.data_ptr(), params.flat.numel(), self.lr, self.b1, self.b2, self.eps,
+                                      state.step, _stream_ptr(dev)), "cnf_adam_step")
     # the kernel wrote params.flat behind torch's back: engines must re-prepare (FlowEngine.load)
     mark_updated(params.flat)
     return state
 
 
-def make_update(loss_fn: Callable, optimizer: Adam, batch_size: int) -> Callable:
+class CapturedUpdate:
+  """`update` of solvers.py:90-97 as ONE device-side program -- what the reference's jitted step is: value_and_grad
+  + Adam captured into a HIP graph on the first calls and replayed afterwards (a default-config step is ~20 small
+  launches: launch latency, not kernels).  Everything that changes from step to step is read from device memory:
+  the step's key (one 8-byte copy per call), the time batch, the mixture components and the base noise drawn from it
+  by kernels, Adam's step count (include/cnf_ot_amd.h, "a training step as one device-side program").
+
+  Same call surface as the eager update: (params, rng, _lambda, opt_state) -> (loss, params, opt_state), with
+  `params` / `opt_state` updated in place and `loss` a 0-dim device tensor that the NEXT call overwrites.  The
+  graph holds the addresses of `params.flat` and of the optimiser state and the value of `_lambda`: call it with the
+  same objects (checked).  `replay=False` runs the very same body eagerly (what the graph is compared with)."""
+
+  WARMUP = 2       # eager steps before the capture: allocations (gradient slabs, cached weight vectors) happen there
+
+  def __init__(self, loss_fn: Callable, optimizer: Adam, batch_size: int, replay: bool = True):
+    self.vg = applications.value_and_grad(loss_fn)
+    self.opt, self.B, self.replay = optimizer, batch_size, replay
+    self.rng, self.graph, self.loss, self._key, self._calls = None, None, None, None, 0
+
+  def _body(self, params, _lambda, opt_state):
+    dev = params.flat.device
+    with torch.cuda.device(dev):
+      _capi.check(_capi.lib().cnf_step_begin(self.rng.ptr, _stream_ptr(dev)), "cnf_step_begin")
+    loss, grads = self.vg(params, self.rng, _lambda, self.B)
+    self.opt.apply(params, grads, opt_state, step_state=self.rng.state)
+    return loss
+
+  def __call__(self, params: Params, rng, _lambda, opt_state: AdamState):
+    if self.rng is None:
+      self.rng = DeviceRng(params.flat.device)
+    key = (params.flat.data_ptr(), opt_state.mu.data_ptr(), opt_state.nu.data_ptr(), float(_lambda))
+    if self._key is not None and key != self._key:
+      raise ValueError("CapturedUpdate was captured for other parameter / optimiser tensors or another _lambda")
+    self._key = key
+    self.rng.set_key(rng)
+    self._calls += 1
+    if not self.replay or self._calls <= self.WARMUP:
+      self.loss = self._body(params, _lambda, opt_state)
+    elif self.graph is None:
+      torch.cuda.synchronize(params.flat.device)
+      graph = torch.cuda.CUDAGraph()
+      step0 = opt_state.step
+      with torch.cuda.graph(graph):
+        self.loss = self._body(params, _lambda, opt_state)
+      opt_state.step = step0            # (the capture only recorded the step)
+      self.graph = graph
+      graph.replay()
+      opt_state.step += 1
+    else:
+      self.graph.replay()
+      opt_state.step += 1
+    return self.loss, params, opt_state
+
+
+def make_update(loss_fn: Callable, optimizer: Adam, batch_size: int, capture: bool = False) -> Callable:
   """`update` of solvers.py:90-97.  The reference returns new pytrees; here the
   parameters and the optimiser state are updated IN PLACE (the same objects are
-  returned), which is what `params, opt_state = update(...)` callers expect."""
+  returned), which is what `params, opt_state = update(...)` callers expect.
+  capture=True: the step as one replayed HIP graph (CapturedUpdate)."""
+  if capture:
+    return CapturedUpdate(loss_fn, optimizer, batch_size)
   vg = applications.value_and_grad(loss_fn)
 
   def update(params: Params, rng, _lambda, opt_state: AdamState) -> Tuple[torch.Tensor, Params, AdamState]:
@@ -113,22 +176,23 @@ def make_update(loss_fn: Callable, optimizer: Adam, batch_size: int) -> Callable
   return update
 
 
-def train(config, epochs: int = None, log=None):
+def train(config, epochs: int = None, log=None, capture: bool = False):
   """The training loop of solvers.py:99-127 without tqdm/plots: returns
-  (params, loss history as a list of 0-dim device tensors)."""
+  (params, loss history as a list of 0-dim device tensors).  capture=True: every step after the first two is the
+  replay of one HIP graph (CapturedUpdate)."""
   model = build_model(config)
   seed = int(config["general"]["seed"])
   params = model.init(seed)
   opt = Adam(config["train"]["lr"])
   state = opt.init(params)
-  update = make_update(bind_loss(config, model), opt, config["train"]["batch_size"])
+  update = make_update(bind_loss(config, model), opt, config["train"]["batch_size"], capture=capture)
   n = config["train"]["epochs"] if epochs is None else epochs
   hist = []
   for step in range(n):
     # update_rng, rng = jax.random.split(rng) (solvers.py:104): an independent Philox key per step
     step_rng = (seed + 0x9E3779B97F4A7C15 * (step + 1)) & 0xFFFFFFFFFFFFFFFF
     loss, params, state = update(params, step_rng, config["train"]["_lambda"], state)
-    hist.append(loss)
+    hist.append(loss.clone() if capture else loss)       # (a captured step overwrites its loss tensor)
     if log is not None and step % config["train"]["eval_frequency"] == 0:
       log(step, float(loss))
   return model, params, hist

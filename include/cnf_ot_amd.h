@@ -407,6 +407,31 @@ int cnf_adam_step(float *params, const float *grad, float *mu, float *nu,
                   int64_t n, float lr, float b1, float b2, float eps,
                   int64_t step, void *stream);
 
+/* ---- a training step as ONE device-side program (cnf_ot/mfc/solvers.py:90-105: the reference's step is one jitted
+ * XLA program; here: one HIP graph, captured once and replayed) ----------------------------------------------------
+ * What changes from step to step must not be a kernel argument of a captured step: the random key and the step
+ * count live in device memory, `state` = uint64[2] = { step count, key }.  The caller writes state[1] (one 8-byte
+ * copy) before a step; cnf_step_begin increments the count; the draws below read the key on the device:
+ *   cnf_fill_normal_dev     out[i] = element first_element + i of the cnf_fill_normal stream of the key
+ *                           (base noise; conditional.py:378,399)
+ *   cnf_fill_uniform_dev    out[i] = scale * uniform[0, 1)        (the time batch, applications.py:392,414,434)
+ *   cnf_mixture_source_dev  out[i, :] = z[i, :] + centre of a uniformly drawn component of the 8-mode source
+ *                           (dim 2; applications.py:34-71); comp (optional) receives the component indices
+ * cnf_adam_step_dev is cnf_adam_step with `step` = state[0]; cnf_weighted_sum (out = sum v[i] w[i], one block, fixed
+ * order) composes a loss from its terms' partial sums without a BLAS call inside the capture. */
+int cnf_step_begin(uint64_t *state, void *stream);
+int cnf_fill_normal_dev(const uint64_t *state, uint64_t first_element, int64_t n,
+                        float *out, void *stream);
+int cnf_fill_uniform_dev(const uint64_t *state, uint64_t first, int64_t n,
+                         float scale, float *out, void *stream);
+int cnf_mixture_source_dev(const uint64_t *state, uint64_t first_sample, int64_t n,
+                           const float *z, float *out, int32_t *comp, void *stream);
+int cnf_adam_step_dev(float *params, const float *grad, float *mu, float *nu,
+                      int64_t n, float lr, float b1, float b2, float eps,
+                      const uint64_t *state, void *stream);
+int cnf_weighted_sum(const double *v, const double *w, int64_t n, double *out,
+                     void *stream);
+
 const char *cnf_strerror(int code);
 /* "gfx950" etc.: the offload arch this library was compiled for. */
 const char *cnf_build_arch(void);

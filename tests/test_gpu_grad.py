@@ -203,6 +203,62 @@ def test_adam_step_and_training_decreases_loss(dev):
   assert np.isfinite(last) and last < first
 
 
+@pytest.mark.parametrize("kind", ["ot", "rwpo"])
+def test_captured_step_equals_the_eager_step_bit_for_bit(dev, kind):
+  """solvers.CapturedUpdate: `update` (solvers.py:90-97) captured into one HIP graph -- key, time batch, mixture
+  components, base noise and Adam's step count all read from device memory -- against the very same body run
+  eagerly: after 10 steps from the same start the parameters and both Adam moments are the same BITS, and every
+  step's loss too."""
+  from cnf_ot_amd import solvers
+  ov = {"general": {"type": kind, "t_batch_size": 2}, "train": {"batch_size": 2048, "lr": 1e-3}}
+  config = solvers.load_config(overrides=ov)
+  res = []
+  for replay in (False, True):
+    model = solvers.build_model(config)
+    params = model.init(7)
+    params.flat.add_(0.05 * torch.randn(params.flat.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1)))
+    opt = solvers.Adam(1e-3); st = opt.init(params)
+    upd = solvers.CapturedUpdate(solvers.bind_loss(config, model), opt, 2048, replay=replay)
+    losses = []
+    for step in range(10):
+      loss, params, st = upd(params, 1000 + 17 * step, 5000.0, st)
+      losses.append(loss.clone())
+    torch.cuda.synchronize()
+    assert (upd.graph is not None) == replay and st.step == 10
+    res.append((params.flat.clone(), st.mu.clone(), st.nu.clone(), torch.stack(losses)))
+  for a, b in zip(res[0], res[1]):
+    assert torch.equal(a, b)
+  assert torch.isfinite(res[0][3]).all() and res[0][3][0] != res[0][3][1]      # a new key (new draws) every step
+
+
+def test_device_drawn_step_inputs_against_the_oracle(dev):
+  """The draws of a captured step (cnf_fill_uniform_dev / cnf_mixture_source_dev / cnf_fill_normal_dev, keyed from
+  device memory): read back and fed to the float64 restatement of applications.py -- the OT loss of a DeviceRng call
+  is the oracle's loss on those very inputs; and the noise is the cnf_fill_normal stream of the same key."""
+  import oracle
+  from oracle import losses as ol
+  from cnf_ot_amd import FlowConfig, FlowModel, Params, DeviceRng, applications as app, _capi
+  from cnf_ot_amd.flows import _stream_ptr
+  cfg = FlowConfig(dim=2); model = FlowModel(cfg)
+  params = Params.random(cfg, 0.2, seed=4, device=dev)
+  B, tbs, key = 4096, 3, 0x123456789ABCDEF1
+  rng = DeviceRng(dev).set_key(key)
+  tb = app.draw_t_batch(rng, tbs).cpu().numpy().astype(np.float64)
+  assert tb.min() >= 0.0 and tb.max() < 1.0 and len(set(tb.tolist())) == tbs
+  comp = torch.empty(B, dtype=torch.int32, device=dev)
+  _capi.check(_capi.lib().cnf_mixture_source_dev(rng.ptr, 0, B, None, None, comp.data_ptr(), _stream_ptr(dev)), "comp")
+  comp = comp.cpu().numpy().astype(np.int64)
+  assert comp.min() == 0 and comp.max() == 7 and np.bincount(comp, minlength=8).min() > B / 8 * 0.7
+  eng = model.terms_backend(params)
+  assert torch.equal(eng.normal(rng, B), eng.normal(key, B))
+  got = float(app.ot_loss_fn(model, 2, 1.0, 0.01, tbs, "free", params, rng, 5000.0, B, source="mixture"))
+  flow = ol.OracleFlow(oracle.OracleConfig(D=2), params.flat.cpu().double().numpy())
+  z = eng.normal(key, B).cpu().double().numpy()
+  want = ol.ot_loss_fn(flow, 2, 1.0, 0.01, "free", 5000.0, B, z, tb, "mixture", comp)
+  print(f"\n[device draws] ot loss {got:.8g} vs oracle {want:.8g}")
+  assert abs(got - want) <= 2e-5 * abs(want)
+
+
 def test_jacobian_helpers_match_finite_differences(dev):
   """forward_jac / inverse_jac / gauge_potential (flows.py:203-211) against
   central differences of the float64 oracle."""
