@@ -524,17 +524,33 @@ def workload_main(args, dev, dist, world, rank, barrier, max_over_ranks):
   sample-sharded over the ranks, ONE sum all-reduce of [partial sums, gradient] per step (RCCL through
   torch.distributed; applications._Ctx.reduce)."""
   step, f, params, B, passes, desc = _config_steps(dev, args.workload, world)
-  for _ in range(max(args.warmup, 1)):
-    loss = step()
-  barrier()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    loss = step()
-  torch.cuda.synchronize()
-  elapsed = time.perf_counter() - t0
-  if dist is not None:
-    dist.barrier()
-  elapsed = max_over_ranks(elapsed)
+  from cnf_ot_amd import applications as app
+
+  def timed():
+    for _ in range(max(args.warmup, 1)):
+      loss = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      loss = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+      dist.barrier()
+    return max_over_ranks(el), loss
+
+  modes = None
+  if args.workload == "cfg5" and world > 1:
+    # configs[4] "allreduce/compute overlap": the density-fit terms' all-reduce under the kinetic / obstacle slices
+    # (shipped default) against ONE blocking collective at the end -- both timed, the same way
+    app.OVERLAP_ALLREDUCE = False
+    el_block, _ = timed()
+    app.OVERLAP_ALLREDUCE = True
+    elapsed, loss = timed()
+    modes = {"overlapped_ms_per_step": elapsed / args.steps * 1e3, "blocking_ms_per_step": el_block / args.steps * 1e3,
+             "shipped": "overlapped"}
+  else:
+    elapsed, loss = timed()
   assert torch.isfinite(torch.as_tensor(loss)).all(), "non-finite loss"
   line = {
     "metric": "flow passes/sec through update() (value_and_grad + Adam) of " + args.workload,
@@ -547,6 +563,8 @@ def workload_main(args, dev, dist, world, rank, barrier, max_over_ranks):
                "comm": args._comm},
     "loss": float(loss),
   }
+  if modes:
+    line["allreduce"] = modes
   if rank == 0:
     print(json.dumps(line), flush=True)
   if dist is not None:

@@ -92,6 +92,7 @@ class _Ctx:
     self.grad = grad
     self._noise = {}
     self._passes = []       # base -> data backward passes waiting for ONE launch (defer_pass_vjp)
+    self._grad64 = None     # the reduced gradient of the last `reduce`, in float64
     # the terms' per-slice sums land side by side in one buffer: `reduce` needs no concatenation kernel
     self._sumbuf = torch.empty(256, dtype=torch.float64, device=self.be.device) if hasattr(self.be, "device") and \
         getattr(self.be.device, "type", "cpu") == "cuda" else None
@@ -163,28 +164,63 @@ class _Ctx:
       ldbar = torch.cat([p[4] if p[4] is not None else torch.zeros(p[0].shape[0], device=z.device) for p in passes])
     be.pass_vjp(z, be.slice_conds(conds), ybar, ldbar, False, grad=self.grad, want_xbar=False)
 
-  def reduce(self, sums: Sequence[torch.Tensor]) -> torch.Tensor:
-    """The ONE collective of a loss evaluation: partial sums (+ the gradient)."""
-    self.flush_passes()
+  def _stack(self, sums: Sequence[torch.Tensor]):
+    """The partial sums of some terms as one float64 vector (a view of the sums buffer when they sit side by side)."""
     parts = [s.reshape(-1).to(torch.float64) for s in sums]
     n = sum(p.numel() for p in parts)
-    if self._sumbuf is not None and len(parts) > 1:      # side by side in the sums buffer already: no concatenation
-      ptr, ok = parts[0].data_ptr(), parts[0].data_ptr() == self._sumbuf.data_ptr()
+    if self._sumbuf is not None and len(parts) > 1:
+      base = self._sumbuf.data_ptr()
+      off = parts[0].data_ptr() - base
+      ptr, ok = parts[0].data_ptr(), 0 <= off and off + 8 * n <= 8 * self._sumbuf.numel()
       for q in parts:
         ok = ok and q.data_ptr() == ptr
         ptr += 8 * q.numel()
       if ok:
-        parts = [self._sumbuf[:n]]
-    if self.grad is not None and self.shard.world > 1:
-      flat = all_reduce_sums(torch.cat(parts + [self.grad.to(torch.float64)]), self.shard)
-      self.grad.copy_(flat[n:].to(torch.float32))
-      return flat[:n]
-    return all_reduce_sums(torch.cat(parts) if len(parts) > 1 else parts[0], self.shard)
+        return self._sumbuf[off // 8:off // 8 + n], n
+    return (torch.cat(parts) if len(parts) > 1 else parts[0]), n
 
-  def combine(self, sums: Sequence[torch.Tensor], coefs: Sequence[float]) -> torch.Tensor:
-    """sum_i coefs[i] * sums[i].sum() after the collective: one dot product with a cached weight vector instead
-    of a slice / sum / multiply / add chain of tiny kernels per term (each costs a launch: 4-5 us on the stream)."""
-    flat = self.reduce(sums)
+  def reduce(self, sums: Sequence[torch.Tensor]) -> torch.Tensor:
+    """The ONE collective of a loss evaluation: partial sums (+ the gradient)."""
+    self.flush_passes()
+    flat, n = self._stack(sums)
+    if self.grad is not None and self.shard.world > 1:
+      flat = all_reduce_sums(torch.cat([flat, self.grad.to(torch.float64)]), self.shard)
+      self._grad64 = flat[n:]
+      self.grad.copy_(flat[n:].to(self.grad.dtype))
+      return flat[:n]
+    return all_reduce_sums(flat, self.shard)
+
+  # -- the collective of the FIRST terms under the compute of the later ones (config 5: BASELINE.json configs[4]) -----
+  def reduce_begin(self, sums: Sequence[torch.Tensor]):
+    """Start the sum all-reduce of the terms evaluated so far -- their partial sums and the gradient accumulated so
+    far -- WITHOUT waiting for it (async_op: RCCL runs it on its own stream behind an event, gloo on a worker thread);
+    the terms that follow accumulate into a fresh gradient buffer, and `reduce_end` folds the two.  With one rank
+    nothing is started."""
+    self.flush_passes()
+    flat, n = self._stack(sums)
+    work, g0 = None, self.grad
+    if self.shard.world > 1:
+      import torch.distributed as dist
+      flat = torch.cat([flat, g0.to(torch.float64)]) if g0 is not None else flat.clone()
+      work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.shard.group, async_op=True)
+      if g0 is not None:
+        self.grad = torch.zeros_like(g0)
+    return flat, work, n, g0
+
+  def reduce_end(self, handle) -> torch.Tensor:
+    """Wait for `reduce_begin`'s collective (call it after the `reduce` of the later terms): the reduced sums of the
+    first terms; the caller's gradient tensor receives first-phase + later-phase gradient."""
+    flat, work, n, g0 = handle
+    if work is not None:
+      work.wait()
+      if g0 is not None:      # first-phase + later-phase gradient, added in float64 and rounded once
+        g0.copy_((flat[n:] + self._grad64).to(g0.dtype))
+        self.grad = g0
+    return flat[:n]
+
+  def weighted(self, flat: torch.Tensor, sums: Sequence[torch.Tensor], coefs: Sequence[float]) -> torch.Tensor:
+    """sum_i coefs[i] * (reduced) sums[i].sum(): one dot product with a cached weight vector instead of a slice /
+    sum / multiply / add chain of tiny kernels per term (each costs a launch: 4-5 us on the stream)."""
     key = (tuple((float(c), int(s.numel())) for c, s in zip(coefs, sums)), str(flat.device))
     w = _WEIGHTS.get(key)
     if w is None:
@@ -199,6 +235,26 @@ class _Ctx:
                                                  _stream_ptr(flat.device)), "cnf_weighted_sum")
       return out[0]
     return torch.dot(flat, w)
+
+  def combine(self, sums: Sequence[torch.Tensor], coefs: Sequence[float]) -> torch.Tensor:
+    """The loss from all its terms' partial sums, after the one collective."""
+    return self.weighted(self.reduce(sums), sums, coefs)
+
+  def combine_overlapped(self, first: Sequence[torch.Tensor], c_first: Sequence[float], later, c_later):
+    """`combine` with the collective of the `first` terms already in flight while `later()` -- a callable that
+    evaluates the remaining terms and returns their sums -- runs; a second, blocking collective for those."""
+    h = self.reduce_begin(first)
+    late = later()
+    flat_late = self.reduce(late)
+    flat_first = self.reduce_end(h)
+    return self.weighted(torch.cat([flat_first, flat_late]), list(first) + list(late), list(c_first) + list(c_later))
+
+
+# Sample-sharded value_and_grad of ot_loss_fn: start the all-reduce of the two density-fit terms (sums + their share
+# of the gradient) as soon as they are done and run the t_batch_size kinetic / obstacle slices under it (BASELINE.json
+# configs[4] "allreduce/compute overlap"); a second collective carries the rest.  False: ONE blocking collective at the
+# end.  Both give the same loss and gradient (tests/test_distributed_cpu.py); see DESIGN.md 7 for what each costs.
+OVERLAP_ALLREDUCE = True
 
 
 _WEIGHTS = {}
@@ -478,17 +534,25 @@ def flow_matching_loss_fn(model, dim, a, sigma, subtype, dt, dx, params, cond, r
 # ---- composite losses ---------------------------------------------------------
 
 def ot_loss_fn(model, dim, T, dt, t_batch_size, subtype, params, rng, _lambda, batch_size,
-               source="mixture", shard=None, grad=None):
-  """applications.py:377-402"""
+               source="mixture", shard=None, grad=None, overlap=None):
+  """applications.py:377-402.  overlap (sharded value_and_grad only; default OVERLAP_ALLREDUCE): the density-fit
+  terms' all-reduce runs under the kinetic / obstacle slices."""
   ctx = _Ctx(model, params, rng, shard, grad)
   t_batch = draw_t_batch(rng, t_batch_size)
   sub = batch_size // 32
   c_kl, c_kin = _lambda / batch_size, 0.5 / (sub * t_batch_size)
-  sums = [_kl_sum(ctx, T, 0.0, batch_size, source, c_kl), _kl_sum(ctx, T, float(T), batch_size, source, c_kl),
-          _kinetic_sum(ctx, dt, t_batch, sub, c_kin)]
-  if subtype == "obstacle":      # summed, not averaged, over slices (applications.py:397-400)
-    sums.append(_potential_sum(ctx, 0.0, "obstacle", t_batch, sub, 1.0 / sub))
-  return ctx.combine(sums, [c_kl, c_kl, c_kin] + ([1.0 / sub] if subtype == "obstacle" else []))
+  first = [_kl_sum(ctx, T, 0.0, batch_size, source, c_kl), _kl_sum(ctx, T, float(T), batch_size, source, c_kl)]
+
+  def later():
+    sums = [_kinetic_sum(ctx, dt, t_batch, sub, c_kin)]
+    if subtype == "obstacle":      # summed, not averaged, over slices (applications.py:397-400)
+      sums.append(_potential_sum(ctx, 0.0, "obstacle", t_batch, sub, 1.0 / sub))
+    return sums
+
+  c_later = [c_kin] + ([1.0 / sub] if subtype == "obstacle" else [])
+  if (OVERLAP_ALLREDUCE if overlap is None else overlap) and ctx.shard.world > 1 and ctx.grad is not None:
+    return ctx.combine_overlapped(first, [c_kl, c_kl], later, c_later)
+  return ctx.combine(first + later(), [c_kl, c_kl] + c_later)
 
 
 def rwpo_loss_fn(model, dim, T, beta, dt, dx, t_batch_size, subtype, a, params, rng, _lambda, batch_size,

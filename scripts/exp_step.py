@@ -1,7 +1,7 @@
 """One training step at the reference's default size (config/mfc.yaml:35-40: batch 2 048), OT: eager `update`
 (host draws), the device-keyed body run eagerly, and the same body replayed from ONE HIP graph (solvers.CapturedUpdate)."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cnf_ot_amd import solvers
 config = solvers.load_config(overrides={"general": {"type": "ot", "t_batch_size": 1}})

@@ -1,0 +1,10 @@
+"""The captured default-config training step under rocprofv3 --kernel-trace --stats: which kernels a step is made of."""
+import sys
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cnf_ot_amd import solvers
+config = solvers.load_config(overrides={"general": {"type": "ot", "t_batch_size": 1}})
+m = solvers.build_model(config); p = m.init(1); opt = solvers.Adam(1e-3); st = opt.init(p)
+upd = solvers.CapturedUpdate(solvers.bind_loss(config, m), opt, 2048)
+for i in range(203): upd(p, i + 1, 5000.0, st)
+torch.cuda.synchronize()

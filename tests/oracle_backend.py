@@ -56,6 +56,28 @@ class OracleBackend:
     return torch.from_numpy(out)
 
 
+  # value_and_grad plumbing on the CPU: the gradient of the term's sum by central differences of the oracle, on a
+  # fixed subset of the parameters (the rest stay zero) -- enough to check that sharded gradients are reduced,
+  # phased (reduce_begin / reduce_end) and composed like single-rank ones
+  GRAD_SUBSET = np.arange(0, 1200, 37)
+
+  def loss_terms_grad(self, spec, pts, t, B, shared, scale, grad, sums=None):
+    base = self.loss_terms(spec, pts, t, B, shared)
+    p0 = self.flow.params.copy()
+    h = 1e-6
+    g = np.zeros(grad.numel())
+    for i in self.GRAD_SUBSET[self.GRAD_SUBSET < grad.numel()]:
+      vals = []
+      for sgn in (1.0, -1.0):
+        q = p0.copy(); q[i] += sgn * h
+        self.flow = ol.OracleFlow(self.flow.cfg, q)
+        vals.append(float(self.loss_terms(spec, pts, t, B, shared).sum()))
+      g[i] = (vals[0] - vals[1]) / (2 * h)
+    self.flow = ol.OracleFlow(self.flow.cfg, p0)
+    grad.add_(torch.from_numpy(scale * g).to(grad.dtype))
+    return base
+
+
 class OracleModel:
   """Duck-types cnf_ot_amd.FlowModel for the loss / evaluator code."""
 

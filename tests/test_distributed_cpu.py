@@ -88,6 +88,56 @@ def test_two_rank_gloo_matches_single_rank(oracle_lib):
       assert abs(results[rank][k] - v) <= 1e-9 * max(1.0, abs(v)), (rank, k, results[rank][k], v)
 
 
+def _vg_worker(rank, world, port, q):
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    from oracle_backend import OracleModel
+    cfg = FlowConfig(dim=2)
+    params = Params.random(cfg, 0.2, seed=5)
+    model = OracleModel(cfg)
+    out = {}
+    for name, overlap in (("blocking", False), ("overlapped", True)):
+      g = torch.zeros(cfg.param_count(), dtype=torch.float64)
+      loss = app.ot_loss_fn(model, 2, 1.0, 0.01, 2, "obstacle", params, 42, 5000.0, 256, source="gaussian", grad=g,
+                            overlap=overlap)
+      out[name] = (float(loss), g.numpy().copy())
+    q.put((rank, out))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_overlapped_allreduce_equals_the_blocking_one(oracle_lib):
+  """BASELINE.json configs[4] ("allreduce/compute overlap"): the all-reduce of the density-fit terms started
+  asynchronously under the kinetic / obstacle slices + a second one for those (applications._Ctx.reduce_begin /
+  reduce_end) against ONE blocking collective at the end -- two gloo ranks, loss AND gradient, and both against the
+  single-rank evaluation."""
+  from oracle_backend import OracleModel
+  cfg = FlowConfig(dim=2)
+  params = Params.random(cfg, 0.2, seed=5)
+  g1 = torch.zeros(cfg.param_count(), dtype=torch.float64)
+  l1 = float(app.ot_loss_fn(OracleModel(cfg), 2, 1.0, 0.01, 2, "obstacle", params, 42, 5000.0, 256, source="gaussian",
+                            grad=g1, shard=Shard()))
+  assert np.count_nonzero(g1.numpy()) > 20
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_vg_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  results = dict(q.get(timeout=600) for _ in range(2))
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  scale = np.abs(g1.numpy()).max()
+  for rank in (0, 1):
+    lb, gb = results[rank]["blocking"]
+    lo, go = results[rank]["overlapped"]
+    assert abs(lo - lb) <= 1e-12 * abs(lb) and np.abs(go - gb).max() <= 1e-12 * scale
+    assert abs(lb - l1) <= 1e-9 * abs(l1) and np.abs(gb - g1.numpy()).max() <= 1e-6 * scale      # (finite-difference gradients)
+
+
 def test_host_composition_matches_reference_restatement(oracle_lib):
   """applications.* over the oracle backend == oracle/losses.py (the float64
   restatement of cnf_ot/mfc/applications.py) given the same draws."""
