@@ -74,6 +74,7 @@ SYMBOLS = {
   "cnf_grad_enable": (ctypes.c_int, [_P, _I64]),
   "cnf_loss_terms_grad": (ctypes.c_int, [_P, ctypes.POINTER(CnfLossSpec), _P, ctypes.c_int, _P, _I64, _I64,
                                          ctypes.c_float, _P, _P, _P, _P]),
+  "cnf_loss_terms_grad_multi": (ctypes.c_int, [_P, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
   "cnf_input_vjp": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _I64, _P, _P, _P, _I64, _P]),
   "cnf_pass_vjp": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _P]),
   "cnf_logprob_fd": (ctypes.c_int, [_P, _P, _P, _I64, ctypes.c_float, _P, _I64, _P]),

@@ -92,6 +92,7 @@ class _Ctx:
     self.grad = grad
     self._noise = {}
     self._passes = []       # base -> data backward passes waiting for ONE launch (defer_pass_vjp)
+    self._jobs = []         # fused loss terms waiting for ONE launch (cnf_loss_terms_grad_multi)
     self._grad64 = None     # the reduced gradient of the last `reduce`, in float64
     # the terms' per-slice sums land side by side in one buffer: `reduce` needs no concatenation kernel
     self._sumbuf = torch.empty(256, dtype=torch.float64, device=self.be.device) if hasattr(self.be, "device") and \
@@ -126,8 +127,18 @@ class _Ctx:
       if s is not None:
         kw["sums"] = s
     if self.grad is not None:
+      if "sums" in kw and hasattr(self.be, "loss_terms_grad_multi"):
+        # value_and_grad: the term is QUEUED -- the terms of a loss go out as one launch whose grid their tiles share
+        # (flush_terms, at the latest in `reduce`); nobody reads a term's sums before the collective
+        self._jobs.append((spec, pts, t, B_local, shared, coef, kw["sums"]))
+        return kw["sums"]
       return self.be.loss_terms_grad(spec, pts, t, B_local, shared, coef, self.grad, **kw)
     return self.be.loss_terms(spec, pts, t, B_local, shared, **kw)
+
+  def flush_terms(self):
+    jobs, self._jobs = self._jobs, []
+    if jobs:
+      self.be.loss_terms_grad_multi(jobs, self.grad)
 
   def defer_pass_vjp(self, z, conds, count: int, ybar, ldbar):
     """Queue the backward of a base -> data pass (points z [S * count, D], one condition per slice of `count`
@@ -137,6 +148,7 @@ class _Ctx:
     self._passes.append((z, _conds(conds), int(count), ybar, ldbar))
 
   def flush_passes(self):
+    self.flush_terms()
     passes, self._passes = self._passes, []
     if not passes:
       return

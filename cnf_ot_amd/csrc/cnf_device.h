@@ -1209,13 +1209,15 @@ struct SliceSum {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
   }
-  __device__ __forceinline__ void flush(double* sums) {
-    if (slice >= 0 && (threadIdx.x & 63) == 0 && run != 0.0) unsafeAtomicAdd(sums + slice, run);
+  double* dst = nullptr;      // the sums array `slice` belongs to (a launch may serve several terms)
+  __device__ __forceinline__ void flush() {
+    if (slice >= 0 && (threadIdx.x & 63) == 0 && run != 0.0) unsafeAtomicAdd(dst + slice, run);
     run = 0.0;
   }
+  __device__ __forceinline__ void flush(double* sums) { (void)sums; flush(); }
   // s: the tile's slice (wave-uniform); part: the tile's sum over the wave's lanes (the same in every lane)
   __device__ __forceinline__ void add(double* sums, int64_t s, float part) {
-    if (s != slice) { flush(sums); slice = s; }
+    if (s != slice || sums != dst) { flush(); slice = s; dst = sums; }
     run = uniform(run + (double)part);
   }
 };

@@ -40,16 +40,26 @@ __device__ __forceinline__ void tile_consts(float* lds) {
   for (int i = threadIdx.x; i < 64; i += GTS) lds[ONES_OFF + i] = 1.0f;
 }
 
-struct GradArgs {
-  ModelArgs m;
+// One launch evaluates up to GRAD_MAX_JOBS loss terms ("jobs": the terms of one composite loss, each with its own
+// points, slices and coefficient): their tiles share the grid, so small terms run side by side instead of one
+// under-filled launch after the other (a default-config training step is three launches of 8 tiles each).
+constexpr int GRAD_MAX_JOBS = 4;
+struct GradJob {
   CnfLossSpec spec;
   const float* pts;
   const float* t;
   double* sums;          // [n_slices] loss-term sums (value of value_and_grad)
+  int64_t B, n_slices, pts_slice_stride;
+  int64_t first_tile;    // of this job, in the launch's tile numbering
+  float scale;           // d(total loss) / d(this term's sum)
+};
+struct GradArgs {
+  ModelArgs m;
+  GradJob job[GRAD_MAX_JOBS];
+  int32_t n_jobs;
   float* slabs;          // [gridDim.x * 4][n_params]
   int64_t n_params;
-  int64_t B, n_slices, pts_slice_stride;
-  float scale;           // d(total loss) / d(this term's sum)
+  int64_t n_tiles;       // of all jobs
   uint32_t div_magic;
 };
 
@@ -319,7 +329,6 @@ __global__ __launch_bounds__(GTS_MAX, 2) void grad_kernel(const GradArgs a) {
   tile_consts(lds);
   if (!DFIX) { for (int j = 0; j < GP; ++j) fa_lds[j * GROW + threadIdx.x] = 0.0f; }
   const int tid = threadIdx.x;
-  const int kind = a.spec.kind;
   // (wave-uniform: a scalar register pair, not two vector registers)
   float* gslab = a.slabs + (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (GTS >> 6) + (tid >> 6))) * a.n_params;
   slab_clear(gslab, a.n_params, tid & 63);
@@ -329,22 +338,26 @@ __global__ __launch_bounds__(GTS_MAX, 2) void grad_kernel(const GradArgs a) {
 #pragma unroll
   for (int j = 0; j <= GK; ++j) fa.Db[j] = 0.0f;
 
-  const float dt = a.spec.dt, dx = a.spec.dx, coef = a.spec.coef;
-  const bool score = kind == CNF_TERM_KINETIC_SCORE || kind == CNF_TERM_FLOW_MATCHING;
-  // number of steps of the pass program
-  const int n_steps = kind == CNF_TERM_KINETIC ? 3 : (score ? 3 + 3 * D + 3 : 1);
-
-  const int64_t tiles_per_slice = (a.B + GTS - 1) / GTS;
-  const int64_t n_tiles = tiles_per_slice * a.n_slices;
   SliceSum ssum;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t slice = tile / tiles_per_slice;
-    const int64_t tile_start = (tile - slice * tiles_per_slice) * GTS;
-    const bool valid = tile_start + tid < a.B;
-    const float sc = valid ? a.scale : 0.0f;
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    int jb = 0;
+#pragma unroll
+    for (int q = 1; q < GRAD_MAX_JOBS; ++q) jb += (q < a.n_jobs && tile >= a.job[q].first_tile) ? 1 : 0;
+    const GradJob& J = a.job[jb];
+    const int kind = J.spec.kind;
+    const float dt = J.spec.dt, dx = J.spec.dx, coef = J.spec.coef;
+    const bool score = kind == CNF_TERM_KINETIC_SCORE || kind == CNF_TERM_FLOW_MATCHING;
+    // number of steps of the pass program
+    const int n_steps = kind == CNF_TERM_KINETIC ? 3 : (score ? 3 + 3 * D + 3 : 1);
+    const int64_t tiles_per_slice = (J.B + GTS - 1) / GTS;
+    const int64_t lt = tile - J.first_tile;
+    const int64_t slice = lt / tiles_per_slice;
+    const int64_t tile_start = (lt - slice * tiles_per_slice) * GTS;
+    const bool valid = tile_start + tid < J.B;
+    const float sc = valid ? J.scale : 0.0f;
     __syncthreads();
-    tile_load1(a.pts + slice * a.pts_slice_stride * D, Nn, D, a.div_magic, tile_start, a.B);
-    const float t = a.t[slice];
+    tile_load1(J.pts + slice * J.pts_slice_stride * D, Nn, D, a.div_magic, tile_start, J.B);
+    const float t = J.t[slice];
     __syncthreads();
     float* n_ = Nn + tid;
     float* s0 = St + tid;               // stash 0 column
@@ -390,8 +403,8 @@ __global__ __launch_bounds__(GTS_MAX, 2) void grad_kernel(const GradArgs a) {
           break;
         }
         case R_POT: {
-          const float pa = a.spec.a;
-          if (a.spec.subtype == CNF_POT_DOUBLE_WELL) {
+          const float pa = J.spec.a;
+          if (J.spec.subtype == CNF_POT_DOUBLE_WELL) {
             float sm = 0.0f, sp = 0.0f;
             for (int e = 0; e < D; ++e) { const float r = sL[e * GROW]; sm = fmaf(r - pa, r - pa, sm); sp = fmaf(r + pa, r + pa, sp); }
             lossv = sm * sp * 0.25f;
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(GTS_MAX, 2) void grad_kernel(const GradArgs a) {
           } else {
             float s2 = 0.0f;
             for (int e = 0; e < D; ++e) { const float r = sL[e * GROW]; s2 = fmaf(r, r, s2); }
-            if (a.spec.subtype == CNF_POT_OBSTACLE) {
+            if (J.spec.subtype == CNF_POT_OBSTACLE) {
               lossv = 50.0f * expf(-0.5f * s2);
               for (int e = 0; e < D; ++e) aa[e * GROW] = -sc * lossv * sL[e * GROW];
             } else {
@@ -414,7 +427,7 @@ __global__ __launch_bounds__(GTS_MAX, 2) void grad_kernel(const GradArgs a) {
           const float lp = base_lp(n_, D) - ldsum;
           float s2 = 0.0f;
           for (int e = 0; e < D; ++e) { const float r = sL[e * GROW]; s2 = fmaf(r, r, s2); }
-          const float Tt = a.spec.T, vs = 2.0f / a.spec.beta * (Tt + 1.0f), vt = 2.0f / a.spec.beta;
+          const float Tt = J.spec.T, vs = 2.0f / J.spec.beta * (Tt + 1.0f), vt = 2.0f / J.spec.beta;
           const float ws = (Tt - t) / Tt, wt = t / Tt;
           const float ls = -0.5f * D * logf(6.283185307179586f * vs), lt = -0.5f * D * logf(6.283185307179586f * vt);
           const float as = -0.5f * s2 / vs + ls, at = -0.5f * s2 / vt + lt;
@@ -452,7 +465,7 @@ __global__ __launch_bounds__(GTS_MAX, 2) void grad_kernel(const GradArgs a) {
         case R_LPM: {
           const float lp_minus = base_lp(sL, D) + ldsum;
           float u = fmaf((lp_plus - lp_minus) / dx, coef, v_[dd * GROW]);
-          if (kind == CNF_TERM_FLOW_MATCHING) u -= drift_of<float>(r3, dd, D, GROW, a.spec.subtype, a.spec.a);
+          if (kind == CNF_TERM_FLOW_MATCHING) u -= drift_of<float>(r3, dd, D, GROW, J.spec.subtype, J.spec.a);
           lossv = fmaf(u, u, lossv);
           ubar = 2.0f * sc * u;
           ub[dd * GROW] = ubar;
@@ -467,7 +480,7 @@ __global__ __launch_bounds__(GTS_MAX, 2) void grad_kernel(const GradArgs a) {
           do_bwd = true;
           break;
         case R_R3B:
-          if (kind == CNF_TERM_FLOW_MATCHING) drift_vjp(r3, ub, r3b, D, a.spec.subtype, a.spec.a);
+          if (kind == CNF_TERM_FLOW_MATCHING) drift_vjp(r3, ub, r3b, D, J.spec.subtype, J.spec.a);
           for (int e = 0; e < D; ++e) aa[e * GROW] = r3b[e * GROW];
           do_bwd = true;
           break;
@@ -489,9 +502,9 @@ __global__ __launch_bounds__(GTS_MAX, 2) void grad_kernel(const GradArgs a) {
     float part = valid ? lossv : 0.0f;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    ssum.add(a.sums, slice, part);
+    ssum.add(J.sums, slice, part);
   }
-  ssum.flush(a.sums);
+  ssum.flush();
   // per-bin adjoint sums of the shared `first` spline: wave reduce, one owner write
   float red[GP];
   if (!DFIX) {
@@ -1492,44 +1505,60 @@ extern "C" int cnf_grad_supported(const CnfConfig* c) {
          c->num_layers >= 1 && grad_lds_bytes(c->dim, c->num_layers, 64) <= 160 * 1024;
 }
 
-extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const float* pts, int pts_shared,
-                                   const float* t, int64_t n_slices, int64_t B, float scale, double* sums,
-                                   float* grad, const float* params, void* stream_) {
-  if (!m || !spec || !pts || !t || !sums || !grad || !params || n_slices < 0 || B < 0) return CNF_ERR_INVALID;
-  if (!m->params_set) return CNF_ERR_INVALID;
-  if (!cnf_grad_supported(&m->cfg)) return CNF_ERR_UNSUPPORTED;
-  if (spec->kind < CNF_TERM_KINETIC || spec->kind > CNF_TERM_NEG_LOGPROB) return CNF_ERR_INVALID;
-  const int D = m->cfg.dim, L = m->cfg.num_layers;
+static int check_term(const CnfModel* m, const CnfLossSpec* spec) {
+  if (!spec || spec->kind < CNF_TERM_KINETIC || spec->kind > CNF_TERM_NEG_LOGPROB) return CNF_ERR_INVALID;
+  const int D = m->cfg.dim;
   if (spec->kind <= CNF_TERM_FLOW_MATCHING && !(spec->dt > 0.f)) return CNF_ERR_INVALID;
   if ((spec->kind == CNF_TERM_KINETIC_SCORE || spec->kind == CNF_TERM_FLOW_MATCHING) && !(spec->dx > 0.f)) return CNF_ERR_INVALID;
   if (spec->kind == CNF_TERM_FLOW_MATCHING) {
     if ((spec->subtype == CNF_DRIFT_SMILE || spec->subtype == CNF_DRIFT_NONGRADIENT) && D != 2) return CNF_ERR_INVALID;
     if (spec->subtype == CNF_DRIFT_LORENZ && D != 3) return CNF_ERR_INVALID;
   }
-  hipStream_t stream = (hipStream_t)stream_;
-  if (n_slices == 0) return CNF_OK;
-  if (hipMemsetAsync(sums, 0, sizeof(double) * (size_t)n_slices, stream) != hipSuccess) return CNF_ERR_HIP;
-  if (B == 0) return CNF_OK;
-  if (!m->grad_slabs) return CNF_ERR_INVALID;      // cnf_grad_enable first
-  if (wait_for_params(m, stream) != CNF_OK) return CNF_ERR_HIP;
+  return CNF_OK;
+}
 
-  GradArgs a;
-  a.m = model_args(m); a.spec = *spec; a.pts = pts; a.t = t; a.sums = sums;
-  a.slabs = m->grad_slabs; a.n_params = m->n_params;
-  a.B = B; a.n_slices = n_slices; a.pts_slice_stride = pts_shared ? 0 : B;
-  a.scale = scale; a.div_magic = m->div_magic;
+extern "C" int cnf_loss_terms_grad_multi(CnfModel* m, int32_t n_terms, const CnfLossSpec* specs, const float* const* pts,
+                                         const int32_t* pts_shared, const float* const* t, const int64_t* n_slices,
+                                         const int64_t* B, const float* scale, double* const* sums, float* grad,
+                                         const float* params, void* stream_) {
+  if (!m || n_terms < 1 || n_terms > GRAD_MAX_JOBS || !specs || !pts || !pts_shared || !t || !n_slices || !B || !scale ||
+      !sums || !grad || !params)
+    return CNF_ERR_INVALID;
+  if (!m->params_set) return CNF_ERR_INVALID;
+  if (!cnf_grad_supported(&m->cfg)) return CNF_ERR_UNSUPPORTED;
+  const int D = m->cfg.dim, L = m->cfg.num_layers;
+  hipStream_t stream = (hipStream_t)stream_;
   const bool generic = !(m->fast_math && D == 2);          // (grad_kernel<true, 2> keeps everything in registers)
-  const int ts = pick_tile([&](int t) { return grad_lds_bytes(D, L, t, generic); });
+  const int ts = pick_tile([&](int tt) { return grad_lds_bytes(D, L, tt, generic); });
   const size_t lds = grad_lds_bytes(D, L, ts, generic);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
-  const int64_t n_tiles = ((B + ts - 1) / ts) * n_slices;
+  GradArgs a;
+  a.m = model_args(m); a.slabs = m->grad_slabs; a.n_params = m->n_params; a.div_magic = m->div_magic;
+  a.n_jobs = 0; a.n_tiles = 0;
+  for (int i = 0; i < n_terms; ++i) {
+    const int r = check_term(m, specs + i);
+    if (r != CNF_OK) return r;
+    if (!pts[i] || !t[i] || !sums[i] || n_slices[i] < 0 || B[i] < 0) return CNF_ERR_INVALID;
+    if (n_slices[i] == 0) continue;
+    if (hipMemsetAsync(sums[i], 0, sizeof(double) * (size_t)n_slices[i], stream) != hipSuccess) return CNF_ERR_HIP;
+    if (B[i] == 0) continue;
+    GradJob& J = a.job[a.n_jobs++];
+    J.spec = specs[i]; J.pts = pts[i]; J.t = t[i]; J.sums = sums[i];
+    J.B = B[i]; J.n_slices = n_slices[i]; J.pts_slice_stride = pts_shared[i] ? 0 : B[i];
+    J.scale = scale[i]; J.first_tile = a.n_tiles;
+    a.n_tiles += ((B[i] + ts - 1) / ts) * n_slices[i];
+  }
+  if (a.n_jobs == 0) return CNF_OK;
+  for (int i = a.n_jobs; i < GRAD_MAX_JOBS; ++i) { a.job[i] = a.job[0]; a.job[i].first_tile = a.n_tiles; }
+  if (!m->grad_slabs) return CNF_ERR_INVALID;      // cnf_grad_enable first
+  if (wait_for_params(m, stream) != CNF_OK) return CNF_ERR_HIP;
   const int64_t max_grid = m->grad_max_blocks * 4 / (ts / 64);           // (slabs: one per wave)
   int64_t n_slabs = 0;
   auto launch = [&](auto kernel) -> bool {
     if (!ensure_lds(kernel, lds)) return false;
     int64_t cap = (int64_t)resident_blocks_per_cu(kernel, ts, lds) * m->num_cus;
     if (cap > max_grid) cap = max_grid;
-    const int64_t grid = balanced_grid(n_tiles, cap);
+    const int64_t grid = balanced_grid(a.n_tiles, cap);
     n_slabs = grid * (ts / 64);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(ts), lds, stream, a);
     return true;
@@ -1544,6 +1573,14 @@ extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const f
   hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, n_slabs, m->n_params, params,
                      grad, (double)m->sc.span_eff, (double)m->sc.sp_offset);
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+extern "C" int cnf_loss_terms_grad(CnfModel* m, const CnfLossSpec* spec, const float* pts, int pts_shared,
+                                   const float* t, int64_t n_slices, int64_t B, float scale, double* sums,
+                                   float* grad, const float* params, void* stream_) {
+  if (!spec || !pts || !t || !sums) return CNF_ERR_INVALID;
+  const int32_t shared = pts_shared ? 1 : 0;
+  return cnf_loss_terms_grad_multi(m, 1, spec, &pts, &shared, &t, &n_slices, &B, &scale, &sums, grad, params, stream_);
 }
 
 extern "C" int cnf_grad_enable(CnfModel* m, int64_t max_blocks) {

@@ -415,6 +415,41 @@ class FlowEngine:
                                                  _stream_ptr(self.device)), "cnf_loss_terms_grad")
     return sums
 
+  def loss_terms_grad_multi(self, jobs, grad: torch.Tensor) -> None:
+    """cnf_loss_terms_grad_multi: several terms of one loss in ONE launch.  jobs: (spec, pts, t, B, shared, scale, sums)
+    tuples, at most 4 per launch (longer lists go out in groups); `sums` tensors are filled, `grad` accumulated."""
+    if self._flat is None:
+      raise RuntimeError("load(params) before asking for gradients")
+    if not getattr(self, "_grad_enabled", False):
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
+      self._grad_enabled = True
+    self._check_out(grad, (self.cfg.param_count(),), "grad")
+    C = _capi.ctypes
+    for g0 in range(0, len(jobs), 4):
+      grp = jobs[g0:g0 + 4]
+      n = len(grp)
+      keep = []
+      specs = (_capi.CnfLossSpec * n)()
+      pts_a, t_a, sums_a = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+      shared_a, ns_a, B_a, sc_a = (C.c_int32 * n)(), (C.c_int64 * n)(), (C.c_int64 * n)(), (C.c_float * n)()
+      for i, (spec, pts, t, B, shared, scale, sums) in enumerate(grp):
+        pts = self._points(pts, "loss_terms_grad_multi")
+        t = self.slice_conds(t)
+        need = B if shared else t.numel() * B
+        if pts.shape[0] != need:
+          raise ValueError(f"loss_terms_grad_multi: pts has {pts.shape[0]} rows, expected {need}")
+        if sums.numel() != t.numel() or sums.dtype != torch.float64:
+          raise ValueError("loss_terms_grad_multi: sums must be float64 [n_slices]")
+        keep += [pts, t]
+        specs[i] = spec
+        pts_a[i], t_a[i], sums_a[i] = pts.data_ptr(), t.data_ptr(), sums.data_ptr()
+        shared_a[i], ns_a[i], B_a[i], sc_a[i] = 1 if shared else 0, t.numel(), int(B), float(scale)
+      with torch.cuda.device(self.device):
+        _capi.check(self.lib.cnf_loss_terms_grad_multi(self._h, n, specs, pts_a, shared_a, t_a, ns_a, B_a, sc_a, sums_a,
+                                                       grad.data_ptr(), self._flat.data_ptr(), _stream_ptr(self.device)),
+                    "cnf_loss_terms_grad_multi")
+
   def input_vjp(self, pts, cond, ybar=None, ldbar=None, to_base=False) -> torch.Tensor:
     """cnf_input_vjp: xbar = ybar . dF/dx + ldbar * d logdet/dx of one flow pass."""
     pts = self._points(pts, "input_vjp")

@@ -304,6 +304,18 @@ int cnf_loss_terms_grad(CnfModel *m, const CnfLossSpec *spec, const float *pts,
                         int64_t B, float scale, double *sums, float *grad,
                         const float *params, void *stream);
 
+/* Up to 4 terms of one composite loss (applications.py:377-441) in ONE launch: term i with its own points, slices,
+ * batch and coefficient (arrays of n_terms entries; sums[i] has n_slices[i] doubles).  The terms' tiles share the grid,
+ * so several small terms run side by side instead of one under-filled launch after the other -- a default-config
+ * training step (config/mfc.yaml: batch 2 048) is three terms of 8 tiles each.  Same result as n_terms calls of
+ * cnf_loss_terms_grad up to the order of the float32 additions into `grad`. */
+int cnf_loss_terms_grad_multi(CnfModel *m, int32_t n_terms, const CnfLossSpec *specs,
+                              const float *const *pts, const int32_t *pts_shared,
+                              const float *const *t, const int64_t *n_slices,
+                              const int64_t *B, const float *scale,
+                              double *const *sums, float *grad, const float *params,
+                              void *stream);
+
 /* Replaces the autodiff helpers of the Flow tuple (flows.py:203-211):
  *   forward_jac = vmap(jacfwd(flow.bijector.forward)),
  *   inverse_jac = vmap(jacfwd(flow.bijector.inverse)),
