@@ -429,9 +429,13 @@ def main():
   # each kernel (cnf_model_set_profiling), over min(steps, 8) further steps -- outside the timed region, so
   # the headline number carries no event overhead
   eng.set_profiling(True)
-  for _ in range(min(args.steps, 8)):
+  torch.cuda.synchronize()
+  n_prof = min(args.steps, 8)
+  t0 = time.perf_counter()
+  for _ in range(n_prof):
     step()
   flow_ms, build_ms, launches, prof_samples = eng.read_profile()
+  prof_wall_ms = (time.perf_counter() - t0) * 1e3 / max(n_prof, 1)      # wall time of a PROFILED step (events recorded between the kernels)
   eng.set_profiling(False)
   k_dur = flow_ms * 1e-3 / max(launches, 1)                   # average launch duration of the dominant kernel
   k_samples = prof_samples / max(launches, 1)
@@ -468,6 +472,9 @@ def main():
       "launch_ms": k_dur * 1e3, "launches_timed": launches,
       "samples_per_launch": k_samples, "bytes_per_sample": BYTES_PER_SAMPLE,
       "table_build_ms_per_launch": b_dur * 1e3,
+      # consistency: (launch_ms + table_build_ms_per_launch) x launches per step <= the wall time of a PROFILED step;
+      # a profiled step is a few per cent slower than a timed one (an event record between every two kernels)
+      "profiled_step_ms": prof_wall_ms, "launches_per_step": launches / max(n_prof, 1),
       "timing": "HIP events recorded by the library on the launch stream around each kernel launch "
                 "(cnf_model_set_profiling, include/cnf_ot_amd_debug.h), same calls as the timed region, run right after it",
       "alu_executed": {"flop_per_sample": exec_flop, "achieved": executed_tflops,
@@ -479,7 +486,9 @@ def main():
               "per sample: 2-16-16-16 MLP conditioner + splines).  The table path reads the same conditioner from "
               "exact piecewise-linear tables and executes ~448 flop per sample, so that figure is no longer a bound "
               "(alu_reference_formulation.frac can exceed 1); the bound left is HBM.  What limits the kernel is "
-              "VALU issue (DESIGN.md 5.1d).",
+              "VALU issue (DESIGN.md 5.1d): ~545 vector instructions per 128-sample wave-tile, 96 of them "
+              "quarter-rate transcendentals -> an issue ceiling of ~102 G samples/s for this instruction stream; "
+              "0.22 of the HBM roofline is ~0.85 of that ceiling.",
     },
   }
   pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")

@@ -724,7 +724,7 @@ __device__ __forceinline__ v2f flow2_tables(const float* tab, const float* tbl, 
   return acc;
 }
 
-template <int K, bool TO_BASE, bool FAST, bool PRECISE = false, int LROWS = PWL_LROWS, int LFIX = 0>
+template <int K, bool TO_BASE, bool FAST, bool PRECISE = false, int LROWS = PWL_LROWS, int LFIX = 0, bool SEEDED = false>
 __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs a) {
   const int PWL_THREADS = blockDim.x, PWL_TS = 2 * PWL_THREADS;
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
   const uint32_t lane2 = 2u * (uint32_t)tid;             // the lane's first sample within the tile
   auto tile_points = [&](const Tile& t) {
     f4 x = {0.f, 0.f, 0.f, 0.f};
-    if (!a.in) {             // seeded: the pair's four normals (one Philox block when the pair starts on an even sample)
+    if (SEEDED && !a.in) {   // the pair's four normals (one Philox block when the pair starts on an even sample)
       const uint64_t e0 = (uint64_t)(t.st0 + lane2) * 2u;
       if ((int)lane2 < t.valid) {
         if ((e0 & 3) == 0) {
@@ -1717,6 +1717,8 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
                     : full ? (PwlKernel)cnf::flow_pwl_kernel<5, true, true, true, ALL> : (PwlKernel)cnf::flow_pwl_kernel<5, true, true, true, WIN>)
       : to_base ? (l2 ? (PwlKernel)cnf::flow_pwl_kernel<5, true, true, false, ALL, 2>
                       : full ? (PwlKernel)cnf::flow_pwl_kernel<5, true, true, false, ALL> : (PwlKernel)cnf::flow_pwl_kernel<5, true, true, false, WIN>)
+      : noise ? (l2 ? (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, ALL, 2, true>          // (base noise drawn in the kernel)
+                    : full ? (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, ALL, 0, true> : (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, WIN, 0, true>)
                 : (l2 ? (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, ALL, 2>
                       : full ? (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, ALL> : (PwlKernel)cnf::flow_pwl_kernel<5, false, true, false, WIN>);
   if (!ensure_lds(kern, lds)) return CNF_ERR_UNSUPPORTED;

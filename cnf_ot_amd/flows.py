@@ -117,6 +117,7 @@ class FlowEngine:
     self._flat_key = None
     self._reserved = {}               # stream -> table sets reserved (cnf_model_reserve)
     self._pwl_mode = 1
+    self._precise = True
     self._tables_ok = (cfg.dim == 2 and cfg.hidden_size == 16 and cfg.num_bins == 5 and cfg.mlp_num_layers == 2
                        and not cfg.periodized)
 
@@ -212,6 +213,7 @@ class FlowEngine:
     """cnf_model_set_precise: float64 position path of log_prob / inverse
     (default on), or plain fp32."""
     _capi.check(self.lib.cnf_model_set_precise(self._h, 1 if on else 0), "cnf_model_set_precise")
+    self._precise = bool(on)
 
   def set_samples_per_lane(self, spl: int) -> None:
     """0: chosen by batch size (default); 1 / 2: force the one-sample or the

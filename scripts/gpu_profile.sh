@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes over bench.py: (1) kernel trace + stats of the DRIVER'S command, (2..) PMC counters, each in its
 # own run (no trace domains other than --kernel-trace next to --pmc).  Usage: scripts/gpu_profile.sh <tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
