@@ -152,13 +152,24 @@ __device__ __forceinline__ float table_spline_bwd(const float* tab, float v, flo
   if constexpr (INV) p = rqs_partials_inv<FAST>(v, x0, gather<K>(tab, F_Y0, k), bw, bh, d0, d1, sc.lo, sc.hi);
   else p = rqs_partials<FAST>(v, x0, bw, bh, d0, d1, sc.lo, sc.hi);
   const BinAdjoint a = bin_adjoint<INV, FAST>(p, o_bar, l_bar);
+  // The bin's adjoints into the per-lane accumulators by 0 / 1 masks in FMAs (was: two compare + select pairs per
+  // accumulator, 100 vector instructions per spline; now ~45): ge[j] = [k >= j] is one clamped subtraction each.
+  const float kf = (float)k;
+  float ge[K + 2];
+  ge[0] = 1.0f; ge[K + 1] = 0.0f;
+#pragma unroll
+  for (int j = 1; j <= K; ++j) ge[j] = clip01(kf - (float)(j - 1));
 #pragma unroll
   for (int j = 0; j < K; ++j) {
-    Wb[j] += (j < k ? a.x0 : 0.0f) + (j == k ? a.bw : 0.0f);
-    Hb[j] += (j < k ? a.y0 : 0.0f) + (j == k ? a.bh : 0.0f);
+    const float eq = ge[j] - ge[j + 1];                      // [k == j]
+    Wb[j] = fmaf(ge[j + 1], a.x0, fmaf(eq, a.bw, Wb[j]));    // knots left of the bin move with x0, the bin's own width with bw
+    Hb[j] = fmaf(ge[j + 1], a.y0, fmaf(eq, a.bh, Hb[j]));
   }
 #pragma unroll
-  for (int j = 0; j <= K; ++j) Db[j] += (j == k ? a.d0 : 0.0f) + (j == k + 1 ? a.d1 : 0.0f);
+  for (int j = 0; j <= K; ++j) {
+    const float eq = ge[j] - ge[j + 1], eq1 = j > 0 ? ge[j - 1] - ge[j] : 0.0f;      // [k == j], [k + 1 == j]
+    Db[j] = fmaf(eq, a.d0, fmaf(eq1, a.d1, Db[j]));
+  }
   return a.v;
 }
 

@@ -796,7 +796,7 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
   for (int i = tid; i < L * PWL_ACC_W * PWL_STAT_LDS; i += NT) acc[i] = 0;
   const SplineConsts sc = sc_scalars(a.m.sc);
   // fixed-point scale 2^(28 - e), e = the exponent of the largest adjoint; x -> round(x scale) by the 1.5 2^52 trick
-  const double fx_scale = stat_scale(*a.amax);
+  const double fx_scale = SliceSum::uniform(stat_scale(*a.amax));      // (wave-uniform: a scalar register pair)
   auto to_fixed = [&](double xs) -> stat_t {              // xs = x scale, |xs| < 2^50
     const double d = xs + 6755399441055744.0;
     return (stat_t)(__double_as_longlong(d) - __double_as_longlong(6755399441055744.0));
