@@ -27,7 +27,7 @@ import torch
 
 from . import _capi
 from .distributed import Shard, all_reduce_sums, current_shard, shard_range
-from .flows import DeviceRng, _stream_ptr, seed_to_u64
+from .flows import DeviceRng, _OnDevice, _stream_ptr, seed_to_u64
 
 # Cholesky factor L (lower: A = L L^T, applied as z @ L like oracle/losses.py) of the Gaussian source's covariance A = [[5, 1], [1, .5]]
 # (applications.py:28-32), computed once: torch.linalg.cholesky of a 2 x 2 CPU tensor costs ~20 ms PER CALL on a
@@ -46,8 +46,11 @@ def _spec(kind, subtype=0, dt=0.0, dx=0.0, coef=0.0, a=0.0, T=1.0, beta=1.0):
 
 
 def host_rng(rng, stream: int) -> np.random.Generator:
+  """The host generator of a loss's non-Gaussian draws (time batch: stream 1, mixture components: stream 2), keyed by
+  the loss's `rng`.  (One integer seed into PCG64: np.random.default_rng on a 4-word list costs 40 us per call -- a
+  third of the host time of a config-3 loss evaluation.)"""
   seed, off = seed_to_u64(rng)
-  return np.random.default_rng([seed & 0xFFFFFFFF, seed >> 32, off, stream])
+  return np.random.Generator(np.random.PCG64((seed << 72) | ((off & ((1 << 64) - 1)) << 8) | stream))
 
 
 def draw_t_batch(rng, t_batch_size: int, scale: float = 1.0):
@@ -55,7 +58,7 @@ def draw_t_batch(rng, t_batch_size: int, scale: float = 1.0):
   a device tensor drawn by cnf_fill_uniform_dev from the key in device memory."""
   if isinstance(rng, DeviceRng):
     out = torch.empty(t_batch_size, dtype=torch.float32, device=rng.device)
-    with torch.cuda.device(rng.device):
+    with _OnDevice(rng.device):
       _capi.check(_capi.lib().cnf_fill_uniform_dev(rng.ptr, 0, t_batch_size, float(scale), out.data_ptr(),
                                                    _stream_ptr(rng.device)), "cnf_fill_uniform_dev")
     return out
@@ -242,7 +245,7 @@ class _Ctx:
                                        dtype=torch.float64, device=flat.device)
     if flat.is_cuda:       # one block, fixed order, no BLAS call (and nothing a stream capture could not record)
       out = torch.empty(1, dtype=torch.float64, device=flat.device)
-      with torch.cuda.device(flat.device):
+      with _OnDevice(flat.device):
         _capi.check(_capi.lib().cnf_weighted_sum(flat.data_ptr(), w.data_ptr(), flat.numel(), out.data_ptr(),
                                                  _stream_ptr(flat.device)), "cnf_weighted_sum")
       return out[0]
@@ -280,7 +283,7 @@ def _source_samples(ctx, z, start, count, n_global, source):
       raise ValueError("the mixture source of kl_loss_fn is 2-D (applications.py:40-67)")
     if isinstance(ctx.rng, DeviceRng):
       out = torch.empty_like(z)
-      with torch.cuda.device(z.device):
+      with _OnDevice(z.device):
         _capi.check(_capi.lib().cnf_mixture_source_dev(ctx.rng.ptr, start, count, z.data_ptr(), out.data_ptr(), None,
                                                        _stream_ptr(z.device)), "cnf_mixture_source_dev")
       return out

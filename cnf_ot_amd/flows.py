@@ -42,7 +42,32 @@ def _c_config(cfg: FlowConfig) -> _capi.CnfConfig:
 
 
 def _stream_ptr(device) -> int:
-  return torch.cuda.current_stream(device).cuda_stream
+  """hipStream_t of torch's current stream on `device` (the raw handle: no Stream object per call)."""
+  idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+  if idx is None:
+    idx = torch.cuda.current_device()
+  return torch._C._cuda_getCurrentRawStream(idx)
+
+
+class _OnDevice:
+  """`with torch.cuda.device(dev)` for the C calls (hipcc's runtime acts on the CURRENT device), without the cost of
+  the context manager when `dev` already is current -- every launch of a loss evaluation goes through one of these."""
+  __slots__ = ("dev", "ctx")
+
+  def __init__(self, dev):
+    self.dev, self.ctx = dev, None
+
+  def __enter__(self):
+    if torch.cuda.current_device() != self.dev.index:
+      self.ctx = torch.cuda.device(self.dev)
+      self.ctx.__enter__()
+    return self
+
+  def __exit__(self, *exc):
+    if self.ctx is not None:
+      self.ctx.__exit__(*exc)
+      self.ctx = None
+    return False
 
 
 def seed_to_u64(seed) -> Tuple[int, int]:
@@ -109,7 +134,7 @@ class FlowEngine:
       self.device = torch.device("cuda", torch.cuda.current_device())
     ccfg = _c_config(cfg)
     handle = _capi.ctypes.c_void_p()
-    with torch.cuda.device(self.device):
+    with _OnDevice(self.device):
       _capi.check(self.lib.cnf_model_create(_capi.ctypes.byref(ccfg), _capi.ctypes.byref(handle)),
                   "cnf_model_create")
     self._h = handle
@@ -146,7 +171,7 @@ class FlowEngine:
     key = (flat.data_ptr(), flat._version, _WRITE_EPOCH.get(flat.data_ptr(), 0))
     if assume_unchanged and self._flat is not None and key == self._flat_key:
       return self
-    with torch.cuda.device(self.device):
+    with _OnDevice(self.device):
       _capi.check(self.lib.cnf_model_set_params(self._h, flat.data_ptr(), _stream_ptr(self.device)),
                   "cnf_model_set_params")
     self._flat = flat
@@ -167,7 +192,7 @@ class FlowEngine:
     if want <= have or torch.cuda.is_current_stream_capturing():
       return have
     want = max(16, 1 << (want - 1).bit_length())          # grow geometrically: few re-allocations
-    with torch.cuda.device(self.device):
+    with _OnDevice(self.device):
       _capi.check(self.lib.cnf_model_reserve(self._h, stream, want), "cnf_model_reserve")
     self._reserved[stream] = want
     return want
@@ -271,7 +296,7 @@ class FlowEngine:
     elif want_aux:
       aux = torch.empty(B, dtype=pts.dtype, device=self.device)
     if B > 0:
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(fn(self._h, pts.data_ptr(), c.data_ptr(), c_block,
                        out.data_ptr() if out is not None else None,
                        aux.data_ptr() if aux is not None else None, B,
@@ -299,7 +324,7 @@ class FlowEngine:
     lp = torch.empty(B, dtype=value.dtype, device=self.device)
     if B > 0:
       fn = self.lib.cnf_log_prob_f64 if f64 else self.lib.cnf_log_prob
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(fn(self._h, value.data_ptr(), c.data_ptr(), c_block, lp.data_ptr(), B,
                        _stream_ptr(self.device)), "cnf_log_prob")
     return lp
@@ -333,7 +358,7 @@ class FlowEngine:
     elif want_logp:
       logp_out = torch.empty(B, dtype=torch.float32, device=self.device)
     if B > 0:
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_sample_logprob_seeded(self._h, seed, off + int(first_sample), int(slice_stride),
                                                        c.data_ptr(), c_block, out.data_ptr(),
                                                        logp_out.data_ptr() if logp_out is not None else None, B,
@@ -370,7 +395,7 @@ class FlowEngine:
     if self._pwl_mode and n_slices > 0:
       self.reserve(n_slices, _sets_of(spec))
     if n_slices > 0:
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_loss_terms(self._h, _capi.ctypes.byref(spec), pts.data_ptr(),
                                             1 if shared else 0, t.data_ptr(), n_slices, B,
                                             sums.data_ptr(), _stream_ptr(self.device)), "cnf_loss_terms")
@@ -385,7 +410,7 @@ class FlowEngine:
     if self._pwl_mode and t.numel() > 0:
       self.reserve(t.numel(), _sets_of(spec))
     if t.numel() > 0:
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_loss_terms_seeded(self._h, _capi.ctypes.byref(spec), seed, off + first_sample,
                                                    slice_stride, t.data_ptr(), t.numel(), B, sums.data_ptr(),
                                                    _stream_ptr(self.device)), "cnf_loss_terms_seeded")
@@ -397,7 +422,7 @@ class FlowEngine:
     if self._flat is None:
       raise RuntimeError("load(params) before asking for gradients")
     if not getattr(self, "_grad_enabled", False):
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
       self._grad_enabled = True
     pts = self._points(pts, "loss_terms_grad")
@@ -410,7 +435,7 @@ class FlowEngine:
     if sums is None:
       sums = torch.empty(n_slices, dtype=torch.float64, device=self.device)
     if n_slices > 0:
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_loss_terms_grad(self._h, _capi.ctypes.byref(spec), pts.data_ptr(),
                                                  1 if shared else 0, t.data_ptr(), n_slices, B, float(scale),
                                                  sums.data_ptr(), grad.data_ptr(), self._flat.data_ptr(),
@@ -423,7 +448,7 @@ class FlowEngine:
     if self._flat is None:
       raise RuntimeError("load(params) before asking for gradients")
     if not getattr(self, "_grad_enabled", False):
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
       self._grad_enabled = True
     self._check_out(grad, (self.cfg.param_count(),), "grad")
@@ -447,7 +472,7 @@ class FlowEngine:
         specs[i] = spec
         pts_a[i], t_a[i], sums_a[i] = pts.data_ptr(), t.data_ptr(), sums.data_ptr()
         shared_a[i], ns_a[i], B_a[i], sc_a[i] = 1 if shared else 0, t.numel(), int(B), float(scale)
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_loss_terms_grad_multi(self._h, n, specs, pts_a, shared_a, t_a, ns_a, B_a, sc_a, sums_a,
                                                        grad.data_ptr(), self._flat.data_ptr(), _stream_ptr(self.device)),
                     "cnf_loss_terms_grad_multi")
@@ -465,7 +490,7 @@ class FlowEngine:
         raise ValueError("ldbar must have one value per sample")
     xbar = torch.empty_like(pts)
     if B > 0:
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_input_vjp(self._h, 1 if to_base else 0, pts.data_ptr(), c.data_ptr(), c_block,
                                            ybar.data_ptr() if ybar is not None else None,
                                            ldbar.data_ptr() if ldbar is not None else None,
@@ -484,7 +509,7 @@ class FlowEngine:
       if self._flat is None:
         raise RuntimeError("load(params) before asking for gradients")
       if not getattr(self, "_grad_enabled", False):
-        with torch.cuda.device(self.device):
+        with _OnDevice(self.device):
           _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
         self._grad_enabled = True
       self._check_out(grad, (self.cfg.param_count(),), "grad")
@@ -492,7 +517,7 @@ class FlowEngine:
         self.reserve(min(-(-B // c_block), 64))
     xbar = torch.empty_like(pts) if want_xbar else None
     if B > 0:
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_pass_vjp(self._h, 1 if to_base else 0, pts.data_ptr(), c.data_ptr(), c_block,
                                           ybar.data_ptr() if ybar is not None else None,
                                           ldbar.data_ptr() if ldbar is not None else None,
@@ -509,7 +534,7 @@ class FlowEngine:
     c, c_block = self.cond(cond, B)
     score = torch.empty_like(pts)
     if B > 0:
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_logprob_fd(self._h, pts.data_ptr(), c.data_ptr(), c_block, float(dx),
                                             score.data_ptr(), B, _stream_ptr(self.device)), "cnf_logprob_fd")
     return score
@@ -521,7 +546,7 @@ class FlowEngine:
     if self._flat is None:
       raise RuntimeError("load(params) before asking for gradients")
     if not getattr(self, "_grad_enabled", False):
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
       self._grad_enabled = True
     pts = self._points(pts, "logprob_fd_vjp")
@@ -531,7 +556,7 @@ class FlowEngine:
     self._check_out(grad, (self.cfg.param_count(),), "grad")
     pts_bar = torch.empty_like(pts) if want_pts_bar else None
     if B > 0:
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_logprob_fd_vjp(self._h, pts.data_ptr(), c.data_ptr(), c_block, float(dx),
                                                 gbar.data_ptr(), pts_bar.data_ptr() if want_pts_bar else None,
                                                 grad.data_ptr(), self._flat.data_ptr(), B,
@@ -545,7 +570,7 @@ class FlowEngine:
     if self._flat is None:
       raise RuntimeError("load(params) before asking for gradients")
     if not getattr(self, "_grad_enabled", False):
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
       self._grad_enabled = True
     r = self._points(r, "score_fd_vjp")
@@ -559,7 +584,7 @@ class FlowEngine:
     sums = torch.empty(n // count, dtype=torch.float64, device=self.device)
     rbar = torch.empty_like(r)
     if n > 0:
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_score_fd_vjp(self._h, r.data_ptr(), c.data_ptr(), int(count), float(dt), float(dx),
                                               float(coef), int(drift), float(a), float(loss_coef), sums.data_ptr(),
                                               rbar.data_ptr(), grad.data_ptr(), self._flat.data_ptr(), n,
@@ -574,7 +599,7 @@ class FlowEngine:
     sums = torch.empty(-(-n // count), dtype=torch.float64, device=self.device)
     rbar = torch.empty_like(r) if want_adjoints else None
     sbar = torch.empty_like(score) if want_adjoints else None
-    with torch.cuda.device(self.device):
+    with _OnDevice(self.device):
       _capi.check(self.lib.cnf_score_residual(r.data_ptr(), score.data_ptr(), n, count, D, float(dt), float(coef),
                                               int(drift), float(a), float(loss_coef), sums.data_ptr(),
                                               rbar.data_ptr() if want_adjoints else None,
@@ -591,7 +616,7 @@ class FlowEngine:
     sums = torch.empty(-(-n // count), dtype=torch.float64, device=self.device)
     rbar = torch.empty_like(r) if want_adjoints else None
     auxbar = torch.empty_like(aux) if (want_adjoints and aux is not None) else None
-    with torch.cuda.device(self.device):
+    with _OnDevice(self.device):
       _capi.check(self.lib.cnf_term_residual(int(kind), r.data_ptr(), aux.data_ptr() if aux is not None else None, n,
                                              int(count), D, int(subtype), float(p0), float(loss_coef), sums.data_ptr(),
                                              rbar.data_ptr() if rbar is not None else None,
@@ -605,7 +630,7 @@ class FlowEngine:
     total = torch.empty(1, dtype=torch.float64, device=self.device)
     ybar = torch.empty_like(y) if want_adjoints else None
     lpbar = torch.empty_like(lp) if want_adjoints else None
-    with torch.cuda.device(self.device):
+    with _OnDevice(self.device):
       _capi.check(self.lib.cnf_rkl_residual(y.data_ptr(), lp.data_ptr(), n, D, float(t), float(T), float(beta),
                                             float(loss_coef), total.data_ptr(),
                                             ybar.data_ptr() if want_adjoints else None,
@@ -637,7 +662,7 @@ class FlowEngine:
       f64 = out.data_ptr() if dtype == torch.float64 else None
       if f32 is None and f64 is None:
         raise ValueError("dtype must be float32 or float64")
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_fill_normal_threefry(k0, k1, total * D, first_sample * D, n_samples * D, f32, f64,
                                                       _stream_ptr(self.device)), "cnf_fill_normal_threefry")
     return out
@@ -649,14 +674,14 @@ class FlowEngine:
     if isinstance(seed, DeviceRng):
       out = torch.empty(n_samples, D, dtype=torch.float32, device=self.device)
       if n_samples > 0:
-        with torch.cuda.device(self.device):
+        with _OnDevice(self.device):
           _capi.check(self.lib.cnf_fill_normal_dev(seed.ptr, first_sample * D, n_samples * D, out.data_ptr(),
                                                    _stream_ptr(self.device)), "cnf_fill_normal_dev")
       return out
     seed, off = seed_to_u64(seed)
     out = torch.empty(n_samples, D, dtype=torch.float32, device=self.device)
     if n_samples > 0:
-      with torch.cuda.device(self.device):
+      with _OnDevice(self.device):
         _capi.check(self.lib.cnf_fill_normal(seed, (off + first_sample) * D, n_samples * D,
                                              out.data_ptr(), _stream_ptr(self.device)), "cnf_fill_normal")
     return out

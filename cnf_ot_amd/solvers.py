@@ -12,7 +12,7 @@ from typing import Any, Callable, Dict, Tuple
 import torch
 
 from . import _capi, applications
-from .flows import DeviceRng, RQSFlow, FlowModel, _stream_ptr, mark_updated
+from .flows import DeviceRng, RQSFlow, FlowModel, _OnDevice, _stream_ptr, mark_updated
 from .params import Params
 
 # config/mfc.yaml:6-40 (the checked-in defaults)
@@ -91,7 +91,7 @@ class Adam:
     lib = _capi.lib()
     state.step += 1
     dev = params.flat.device
-    with torch.cuda.device(dev):
+    with _OnDevice(dev):
       if step_state is not None:
         _capi.check(lib.cnf_adam_step_dev(params.flat.data_ptr(), grads.flat.data_ptr(), state.mu.data_ptr(),
                                           state.nu.data_ptr(), params.flat.numel(), self.lr, self.b1, self.b2, self.eps,
@@ -126,7 +126,7 @@ class CapturedUpdate:
 
   def _body(self, params, _lambda, opt_state):
     dev = params.flat.device
-    with torch.cuda.device(dev):
+    with _OnDevice(dev):
       _capi.check(_capi.lib().cnf_step_begin(self.rng.ptr, _stream_ptr(dev)), "cnf_step_begin")
     loss, grads = self.vg(params, self.rng, _lambda, self.B)
     self.opt.apply(params, grads, opt_state, step_state=self.rng.state)

@@ -17,9 +17,9 @@ torch.cuda.synchronize()
 pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable()
-for _ in range(5):
+for _ in range(50):
   vg(params, 42, 5000.0, Bl)
 torch.cuda.synchronize()
 pr.disable()
-print(f"{which} value_and_grad: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms per call")
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+print(f"{which} value_and_grad: {(time.perf_counter() - t0) / 50 * 1e3:.2f} ms per call")
+pstats.Stats(pr).sort_stats("tottime").print_stats(30)
