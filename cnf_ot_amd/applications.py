@@ -365,6 +365,25 @@ def _potential_tables(ctx, z, conds, count, subtype, a, coef):
   return sums
 
 
+def _kinetic_potential_tables(ctx, z, conds, count, dt, c_kin, subtype, a, c_pot):
+  """The kinetic and the potential term of ot_loss_fn's obstacle case (applications.py:392-400: the same draw pushed to
+  t -+ dt/2 and to t) from ONE forward and ONE backward launch over the 3 S slices -- they were two of each."""
+  be = ctx.be
+  th = _conds(conds)
+  S = _n_conds(th)
+  n = S * count
+  half = np.float32(0.5 * dt)
+  c3 = be.slice_conds(_cat_conds([th - half, th + half, th]))
+  z3 = z.repeat(3 * S, 1)
+  r, _ = be.forward_logdet(z3, c3, want_logdet=False)
+  rbar = torch.empty_like(r)
+  kin, _, _ = be.term_residual(_capi.TERM_KINETIC, r[:2 * n], None, count, p0=dt, loss_coef=c_kin, rbar_out=rbar[:2 * n])
+  pot, _, _ = be.term_residual(_capi.TERM_POTENTIAL, r[2 * n:], None, count, subtype=_capi.POTENTIALS[subtype], p0=a,
+                               loss_coef=c_pot, rbar_out=rbar[2 * n:])
+  be.pass_vjp(z3, c3, rbar, None, False, grad=ctx.grad, want_xbar=False)
+  return kin, pot
+
+
 def _kl_sum(ctx, T, cond, batch_size, source, coef):
   z, start, count = ctx.noise(batch_size)
   key = ("source", batch_size, source)       # the same key draws the same source samples for every condition
@@ -566,10 +585,12 @@ def ot_loss_fn(model, dim, T, dt, t_batch_size, subtype, params, rng, _lambda, b
   first = [_kl_sum(ctx, T, 0.0, batch_size, source, c_kl), _kl_sum(ctx, T, float(T), batch_size, source, c_kl)]
 
   def later():
-    sums = [_kinetic_sum(ctx, dt, t_batch, sub, c_kin)]
     if subtype == "obstacle":      # summed, not averaged, over slices (applications.py:397-400)
-      sums.append(_potential_sum(ctx, 0.0, "obstacle", t_batch, sub, 1.0 / sub))
-    return sums
+      z, _, count = ctx.noise(sub)
+      if _use_table_backward(ctx, z.shape[1], count, _n_conds(t_batch), passes=2):      # one forward + one backward launch for both
+        return list(_kinetic_potential_tables(ctx, z, t_batch, count, dt, c_kin, "obstacle", 0.0, 1.0 / sub))
+      return [_kinetic_sum(ctx, dt, t_batch, sub, c_kin), _potential_sum(ctx, 0.0, "obstacle", t_batch, sub, 1.0 / sub)]
+    return [_kinetic_sum(ctx, dt, t_batch, sub, c_kin)]
 
   c_later = [c_kin] + ([1.0 / sub] if subtype == "obstacle" else [])
   if (OVERLAP_ALLREDUCE if overlap is None else overlap) and ctx.shard.world > 1 and ctx.grad is not None:

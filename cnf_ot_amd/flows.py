@@ -608,13 +608,17 @@ class FlowEngine:
     return sums, rbar, sbar
 
   def term_residual(self, kind: int, r, aux, count: int, subtype: int = 0, p0: float = 0.0, loss_coef: float = 0.0,
-                    want_adjoints: bool = True):
+                    want_adjoints: bool = True, rbar_out=None):
     """cnf_term_residual: per-slice sums (float64) of a kinetic / potential / density-fit term from the outputs of
-    its flow launches, and the adjoints (rbar, auxbar) of those outputs."""
+    its flow launches, and the adjoints (rbar, auxbar) of those outputs.  rbar_out: where the adjoints of r go (a
+    view of a larger buffer when several terms share one backward launch)."""
     n = r.shape[0] // (2 if kind == _capi.TERM_KINETIC else 1)
     D = r.shape[1]
     sums = torch.empty(-(-n // count), dtype=torch.float64, device=self.device)
-    rbar = torch.empty_like(r) if want_adjoints else None
+    if rbar_out is not None:
+      rbar = self._check_out(rbar_out, r.shape, "term_residual rbar")
+    else:
+      rbar = torch.empty_like(r) if want_adjoints else None
     auxbar = torch.empty_like(aux) if (want_adjoints and aux is not None) else None
     with _OnDevice(self.device):
       _capi.check(self.lib.cnf_term_residual(int(kind), r.data_ptr(), aux.data_ptr() if aux is not None else None, n,
