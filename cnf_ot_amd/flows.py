@@ -249,6 +249,9 @@ class FlowEngine:
   def _points(self, t, what, keep_f64=False) -> torch.Tensor:
     """float64 points select the float64 kernels (the reference's dtype:
     exact-mode parity, slower); everything else runs in float32."""
+    if torch.is_tensor(t) and t.device == self.device and t.dim() == 2 and t.shape[1] == self.cfg.dim and \
+        t.is_contiguous() and (t.dtype == torch.float32 or (keep_f64 and t.dtype == torch.float64)):
+      return t                       # (the common case: nothing to convert, no torch call made)
     if not torch.is_tensor(t):
       t = torch.as_tensor(np.asarray(t))
     if t.dim() != 2 or t.shape[1] != self.cfg.dim:
@@ -260,9 +263,12 @@ class FlowEngine:
   def cond(self, cond, B: int, dtype=torch.float32) -> Tuple[torch.Tensor, int]:
     """cond -> (flat device tensor, c_block).  [B,1]/[B]: per sample;
     scalar/[1]: broadcast; [S]/[S,1] with B % S == 0: S equal slices."""
-    if not torch.is_tensor(cond):
-      cond = torch.as_tensor(np.asarray(cond, dtype=np.float64))
-    c = cond.to(device=self.device, dtype=dtype).reshape(-1).contiguous()
+    if torch.is_tensor(cond) and cond.device == self.device and cond.dtype == dtype and cond.is_contiguous():
+      c = cond if cond.dim() == 1 else cond.reshape(-1)
+    else:
+      if not torch.is_tensor(cond):
+        cond = torch.as_tensor(np.asarray(cond, dtype=np.float64))
+      c = cond.to(device=self.device, dtype=dtype).reshape(-1).contiguous()
     n = c.numel()
     if n == 0:
       raise ValueError("cond is empty")
