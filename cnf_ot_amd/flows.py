@@ -86,6 +86,9 @@ def seed_to_u64(seed) -> Tuple[int, int]:
   return int(seed) & _MASK64, int(offset)
 
 
+_MULTI_TYPES = {}        # n_terms -> the ctypes array types of cnf_loss_terms_grad_multi's arguments
+
+
 class DeviceRng:
   """A training step's random key in DEVICE memory: `state` = int64[2] = [step count, key] (include/cnf_ot_amd.h,
   "a training step as one device-side program").  Pass it wherever the loss functions take `rng`: base noise, the time
@@ -375,6 +378,8 @@ class FlowEngine:
     """[n_slices] float32 on the device.  Host lists are uploaded once and kept (a loss evaluation asks for the
     same few condition lists -- [0], [T], the step's time batch -- for every term, loss and gradient alike)."""
     if torch.is_tensor(t):
+      if t.device == self.device and t.dtype == torch.float32 and t.is_contiguous():
+        return t if t.dim() == 1 else t.reshape(-1)
       return t.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
     a = np.ascontiguousarray(np.asarray(t, dtype=np.float32).reshape(-1))
     key = a.tobytes()
@@ -458,26 +463,29 @@ class FlowEngine:
         _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
       self._grad_enabled = True
     self._check_out(grad, (self.cfg.param_count(),), "grad")
-    C = _capi.ctypes
     for g0 in range(0, len(jobs), 4):
       grp = jobs[g0:g0 + 4]
       n = len(grp)
+      T = _MULTI_TYPES.get(n)
+      if T is None:        # (ctypes array TYPES are built on first use: creating them per call cost more than the call)
+        C = _capi.ctypes
+        T = _MULTI_TYPES[n] = (_capi.CnfLossSpec * n, C.c_void_p * n, C.c_int32 * n, C.c_int64 * n, C.c_float * n)
+      specs, pts_a, t_a, sums_a = T[0](), T[1](), T[1](), T[1]()
+      shared_a, ns_a, B_a, sc_a = T[2](), T[3](), T[3](), T[4]()
       keep = []
-      specs = (_capi.CnfLossSpec * n)()
-      pts_a, t_a, sums_a = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
-      shared_a, ns_a, B_a, sc_a = (C.c_int32 * n)(), (C.c_int64 * n)(), (C.c_int64 * n)(), (C.c_float * n)()
       for i, (spec, pts, t, B, shared, scale, sums) in enumerate(grp):
         pts = self._points(pts, "loss_terms_grad_multi")
         t = self.slice_conds(t)
-        need = B if shared else t.numel() * B
+        nt = t.numel()
+        need = B if shared else nt * B
         if pts.shape[0] != need:
           raise ValueError(f"loss_terms_grad_multi: pts has {pts.shape[0]} rows, expected {need}")
-        if sums.numel() != t.numel() or sums.dtype != torch.float64:
+        if sums.numel() != nt or sums.dtype != torch.float64:
           raise ValueError("loss_terms_grad_multi: sums must be float64 [n_slices]")
         keep += [pts, t]
         specs[i] = spec
         pts_a[i], t_a[i], sums_a[i] = pts.data_ptr(), t.data_ptr(), sums.data_ptr()
-        shared_a[i], ns_a[i], B_a[i], sc_a[i] = 1 if shared else 0, t.numel(), int(B), float(scale)
+        shared_a[i], ns_a[i], B_a[i], sc_a[i] = 1 if shared else 0, nt, int(B), float(scale)
       with _OnDevice(self.device):
         _capi.check(self.lib.cnf_loss_terms_grad_multi(self._h, n, specs, pts_a, shared_a, t_a, ns_a, B_a, sc_a, sums_a,
                                                        grad.data_ptr(), self._flat.data_ptr(), _stream_ptr(self.device)),
