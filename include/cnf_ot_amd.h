@@ -283,7 +283,7 @@ int cnf_loss_terms_seeded(CnfModel *m, const CnfLossSpec *spec, uint64_t seed,
 
 /* ---- value_and_grad + Adam (cnf_ot/mfc/solvers.py:90-97) -------------------
  * Backward pass of the loss terms, for the reference's network (hidden 16, two
- * hidden layers, 5 bins; dim <= 12 at two flow layers -- the tile's working set
+ * hidden layers, 5 bins; dim <= 14 -- the first layer's inputs + bias row are 16 MFMA rows, and the tile's working set
  * must fit one CU's LDS): cnf_grad_supported() tells.  A model's gradient
  * slabs are shared state: do not run two gradient calls of the same model
  * concurrently on different streams.
