@@ -250,6 +250,11 @@ def test_adam_step_and_training_decreases_loss(dev):
   first, last = float(torch.stack(hist[:5]).mean()), float(torch.stack(hist[-5:]).mean())
   print(f"[train ot] loss {first:.5g} -> {last:.5g} after 60 Adam steps")
   assert np.isfinite(last) and last < first
+  # the same loop with every step after the second replayed from ONE HIP graph (solvers.CapturedUpdate)
+  model, params, hist = solvers.train(config, epochs=60, capture=True)
+  first, last = float(torch.stack(hist[:5]).mean()), float(torch.stack(hist[-5:]).mean())
+  print(f"[train ot, captured step] loss {first:.5g} -> {last:.5g} after 60 Adam steps")
+  assert np.isfinite(last) and last < first
 
 
 @pytest.mark.parametrize("kind", ["ot", "rwpo"])
