@@ -252,6 +252,257 @@ __device__ __forceinline__ float cond_spline_bwd(const float (&th)[3 * K + 1], f
 }
 
 // ---------------------------------------------------------------------------
+// The same derivatives for SAMPLE PAIRS (two samples per lane, v2f): everything but the transcendentals and the
+// table reads is one packed instruction for both samples (vjp_pwl_kernel, the table backward of dim 2).  Same
+// formulas as above; where the single-sample forms select with compares (the bin, the tails) these use the 0 / 1
+// masks of cond_spline_masked in packed FMAs.
+// ---------------------------------------------------------------------------
+struct BinPartials2 {
+  v2f f_x, f_x0, f_bw, f_bh, f_d0, f_d1;
+  v2f l_x, l_x0, l_bw, l_bh, l_d0, l_d1;
+  v2f f_y0;
+};
+
+template <bool FAST>
+__device__ __forceinline__ BinPartials2 rqs_partials_at(v2f z, v2f omz, v2f x, v2f bw, v2f bh, v2f d0, v2f d1,
+                                                        float lo, float hi) {
+  using M = Math<FAST>;
+  BinPartials2 p;
+  const v2f ibw = M::rcp(bw);
+  const v2f s = bh * ibw;
+  const v2f q = z * omz, qp = omz - z;
+  const v2f st = d0 + d1 - s * 2.0f;
+  const v2f Nn = vfma(s * z, z, d0 * q);
+  const v2f den = vfma(st, q, s);
+  const v2f iden = M::rcp(den);
+  const v2f A = vfma(d1 * z, z, vfma(s * 2.0f, q, d0 * omz * omz));
+  const v2f iA = M::rcp(A);
+  const v2f iden2 = iden * iden;
+  p.f_x = s * s * A * iden2;
+  const v2f bq = bh * q * iden2;
+  const v2f f_s = bq * vfma(Nn, splat<v2f>(2.0f), vfma(z * z, st, -d0));
+  p.f_d0 = bq * omz * vfma(s, omz, d1 * z);
+  p.f_d1 = -bq * Nn;
+  p.f_x0 = -p.f_x;
+  const v2f fsi = f_s * ibw;
+  p.f_bw = -vfma(p.f_x, z, fsi * s);
+  p.f_bh = vfma(Nn, iden, fsi);
+  const v2f Az = (vfma(d1, z, s * qp) - d0 * omz) * 2.0f;
+  const v2f denz = st * qp;
+  const v2f l_z = vfma(denz * -2.0f, iden, Az * iA);
+  const v2f l_s = q * 2.0f * vfma((d0 + d1) * iden, M::rcp(s), iA);
+  p.l_x = l_z * ibw;
+  p.l_x0 = -p.l_x;
+  p.l_bw = -vfma(l_z, z, l_s * s) * ibw;
+  p.l_bh = l_s * ibw;
+  const v2f q2i = q * 2.0f * iden;
+  p.l_d0 = vfma(omz * omz, iA, -q2i);
+  p.l_d1 = vfma(z * z, iA, -q2i);
+  p.f_y0 = splat<v2f>(1.0f);
+  if (maybe_outside(x, lo, hi)) {      // (wave-level: rare) the linear tails hang on the fixed corners
+    const v2i below = vle(x, lo), above = vge(x, hi), out = below | above;
+    const v2f zero = splat<v2f>(0.0f);
+    p.f_x = vsel(below, d0, vsel(above, d1, p.f_x));
+    p.f_d0 = vsel(below, x - lo, vsel(above, zero, p.f_d0));
+    p.f_d1 = vsel(above, x - hi, vsel(below, zero, p.f_d1));
+    p.l_d0 = vsel(below, M::rcp(d0), vsel(above, zero, p.l_d0));
+    p.l_d1 = vsel(above, M::rcp(d1), vsel(below, zero, p.l_d1));
+    p.f_x0 = vsel(out, zero, p.f_x0); p.f_bw = vsel(out, zero, p.f_bw); p.f_bh = vsel(out, zero, p.f_bh);
+    p.l_x = vsel(out, zero, p.l_x); p.l_x0 = vsel(out, zero, p.l_x0); p.l_bw = vsel(out, zero, p.l_bw);
+    p.l_bh = vsel(out, zero, p.l_bh); p.f_y0 = vsel(out, zero, p.f_y0);
+  }
+  return p;
+}
+
+struct BinAdjoint2 { v2f v, x0, y0, bw, bh, d0, d1; };
+
+template <bool INV, bool FAST>
+__device__ __forceinline__ BinAdjoint2 bin_adjoint(const BinPartials2& p, v2f o_bar, v2f l_bar) {
+  BinAdjoint2 a;
+  if (!INV) {
+    a.v = vfma(o_bar, p.f_x, l_bar * p.l_x);
+    a.x0 = vfma(o_bar, p.f_x0, l_bar * p.l_x0);
+    a.y0 = o_bar * p.f_y0;
+    a.bw = vfma(o_bar, p.f_bw, l_bar * p.l_bw);
+    a.bh = vfma(o_bar, p.f_bh, l_bar * p.l_bh);
+    a.d0 = vfma(o_bar, p.f_d0, l_bar * p.l_d0);
+    a.d1 = vfma(o_bar, p.f_d1, l_bar * p.l_d1);
+  } else {
+    a.v = vfma(-l_bar, p.l_x, o_bar) * Math<FAST>::rcp(p.f_x);
+    a.x0 = -vfma(p.f_x0, a.v, l_bar * p.l_x0);
+    a.y0 = -a.v * p.f_y0;
+    a.bw = -vfma(p.f_bw, a.v, l_bar * p.l_bw);
+    a.bh = -vfma(p.f_bh, a.v, l_bar * p.l_bh);
+    a.d0 = -vfma(p.f_d0, a.v, l_bar * p.l_d0);
+    a.d1 = -vfma(p.f_d1, a.v, l_bar * p.l_d1);
+  }
+  return a;
+}
+
+// the partials at the point the direction differentiates at: the input (INV = false), or the output of the inverse
+// map, formed here from the bin's own quantities and from the nearer end of the bin (rqs_partials_inv above)
+template <bool INV, bool FAST>
+__device__ __forceinline__ BinPartials2 rqs_partials_dir(v2f v, v2f x0, v2f y0, v2f bw, v2f bh, v2f d0, v2f d1,
+                                                         float lo, float hi) {
+  using M = Math<FAST>;
+  if constexpr (!INV) {
+    const v2f z = clip01((v - x0) * M::rcp(bw));
+    return rqs_partials_at<FAST>(z, 1.0f - z, v, bw, bh, d0, d1, lo, hi);
+  } else {
+    const v2f sl = bh * M::rcp(bw), st = d0 + d1 - sl * 2.0f;
+    const v2f dy = vclamp(v - y0, bh), dyt = bh - dy;
+    const v2i low = vle(dy - dyt, 0.0f);
+    const v2f t = vsel(low, dy, dyt), da = vsel(low, d0, d1);
+    const v2f c = -sl * t, b = vfma(-st, t, da * bh), a2 = vfma(sl, bh, -b);
+    const v2f disc = vfma(b, b, a2 * c * -4.0f);
+    const v2f r = clip01(M::div(c * -2.0f, b + M::sqrt(disc)));
+    const v2f omr = 1.0f - r;
+    const v2f z = vsel(low, r, omr), omz = vsel(low, omr, r);
+    v2f out = vsel(low, vfma(bw, r, x0), vfma(-bw, r, x0 + bw));
+    if (maybe_outside(v, lo, hi)) {
+      out = vsel(vle(v, lo), vfma(v - lo, M::rcp(d0), splat<v2f>(lo)), out);
+      out = vsel(vge(v, hi), vfma(v - hi, M::rcp(d1), splat<v2f>(hi)), out);
+    }
+    return rqs_partials_at<FAST>(z, omz, out, bw, bh, d0, d1, lo, hi);
+  }
+}
+
+// 0 / 1 masks m[j] = [v > knot j] of a sample pair, j = 1 .. K-1 (bin_of_pairs' packed clamp-FMAs; `kb` = the F_XKB /
+// F_YKB field of the prepared table); m[0] = 1, m[K] = 0: the one-hot of the bin is m[j] - m[j+1]
+template <int K> __device__ __forceinline__ void bin_masks_pairs(const float* kb, v2f v, v2f (&m)[K + 1]) {
+  const v2f big = v2f{1.152921504606846976e18f, 1.152921504606846976e18f};       // 2^60
+  m[0] = splat<v2f>(1.0f); m[K] = splat<v2f>(0.0f);
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+    const v2f nk = *reinterpret_cast<const v2f*>(kb + 2 * j);
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(m[j]) : "v"(v), "v"(big), "v"(nk));
+  }
+}
+
+// table_spline_bwd for a sample pair: returns the adjoint of the input, accumulates the pair's bin adjoints into the
+// lane's (pair-wide) per-bin sums
+template <int K, bool INV, bool FAST>
+__device__ __forceinline__ v2f table_spline_bwd(const float* tab, v2f v, v2f o_bar, v2f l_bar, const SplineConsts& sc,
+                                                v2f (&Wb)[K], v2f (&Hb)[K], v2f (&Db)[K + 1]) {
+  v2f m[K + 1];
+  bin_masks_pairs<K>(tab + tab_off(INV ? F_YKB : F_XKB, K), v, m);
+  v2f kf = m[1];
+#pragma unroll
+  for (int j = 2; j < K; ++j) kf += m[j];
+  const BinRow<v2f> row(tab, v2i{(int)kf.x, (int)kf.y});
+  const v2f x0 = row.template get<K>(F_X0), y0 = row.template get<K>(F_Y0), bw = row.template get<K>(F_BW),
+            bh = row.template get<K>(F_BH), d0 = row.template get<K>(F_D0), d1 = row.template get<K>(F_D1);
+  const BinPartials2 p = rqs_partials_dir<INV, FAST>(v, x0, y0, bw, bh, d0, d1, sc.lo, sc.hi);
+  const BinAdjoint2 a = bin_adjoint<INV, FAST>(p, o_bar, l_bar);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const v2f eq = m[j] - m[j + 1];                          // [k == j]
+    Wb[j] = vfma(m[j + 1], a.x0, vfma(eq, a.bw, Wb[j]));     // knots left of the bin move with x0, the bin's own width with bw
+    Hb[j] = vfma(m[j + 1], a.y0, vfma(eq, a.bh, Hb[j]));
+    Db[j] = vfma(eq, a.d0, Db[j]);
+    Db[j + 1] = vfma(eq, a.d1, Db[j + 1]);
+  }
+  return a.v;
+}
+
+// cond_spline_bwd for a sample pair fed from the conditioner tables.  qa / qb: the 2K softmax logits of sample a / b
+// as K pairs (logit 2j, logit 2j + 1) in LOG2 units (pwl_logit_pairs); slopes(ka, kb, ta, tb) returns each sample's
+// (t_k, t_k+1), log2 units with the softplus offset added (pwl_slope_pair).  Writes the adjoints of the 2K logits in
+// NATURAL units to tb (sample pairs), the bin index kk (as floats) and the adjoints sb0 / sb1 of the bin's two slope
+// logits; returns the adjoint of the spline input.  INV: the output is formed here, in the bin selected here.
+template <int K, bool INV, bool FAST, class SlopeFetch>
+__device__ __forceinline__ v2f cond_spline_bwd_rows(const v2f (&qa)[K], const v2f (&qb)[K], SlopeFetch&& slopes, v2f v,
+                                                    v2f o_bar, v2f l_bar, const SplineConsts& sc, v2f (&tb)[2 * K],
+                                                    v2f& kk, v2f& sb0, v2f& sb1) {
+  using M = Math<FAST>;
+  typedef v2f T;
+  auto la = [&](int j) { return qa[j >> 1][j & 1]; };
+  auto lb = [&](int j) { return qb[j >> 1][j & 1]; };
+  float mwa = la(0), mwb = lb(0), mha = la(K), mhb = lb(K);
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    mwa = fmaxf(mwa, la(k)); mwb = fmaxf(mwb, lb(k));
+    mha = fmaxf(mha, la(K + k)); mhb = fmaxf(mhb, lb(K + k));
+  }
+  T pw[K], ph[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    pw[k] = v2f{__builtin_amdgcn_exp2f(la(k) - mwa), __builtin_amdgcn_exp2f(lb(k) - mwb)};
+    ph[k] = v2f{__builtin_amdgcn_exp2f(la(K + k) - mha), __builtin_amdgcn_exp2f(lb(K + k) - mhb)};
+  }
+  T sw = pw[0], sh = ph[0];
+#pragma unroll
+  for (int k = 1; k < K; ++k) { sw += pw[k]; sh += ph[k]; }
+  const T isw = M::rcp(sw), ish = M::rcp(sh);
+#pragma unroll
+  for (int k = 0; k < K; ++k) { pw[k] *= isw; ph[k] *= ish; }      // softmax probabilities
+  const T big = splat<T>(1.152921504606846976e18f);       // 2^60
+  T px = splat<T>(sc.lo), py = splat<T>(sc.lo);            // running knot k
+  T wp = vfma(pw[0], splat<T>(sc.span_eff), splat<T>(sc.min_bin)), hp = vfma(ph[0], splat<T>(sc.span_eff), splat<T>(sc.min_bin));
+  T x0 = px, y0 = py;
+  T m[K + 1];                                              // m[k] = [v > knot k]
+  m[0] = splat<T>(1.0f); m[K] = splat<T>(0.0f);
+  T bw = splat<T>(0.0f), bh = bw, cumw = bw, cumh = bw, pkw = bw, pkh = bw;
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    px += wp;
+    py += hp;
+    m[k] = step_mask(v - (INV ? py : px), big);
+    const T o = m[k - 1] - m[k];                            // one-hot of bin k-1
+    bw = k == 1 ? o * wp : vfma(o, wp, bw);
+    bh = k == 1 ? o * hp : vfma(o, hp, bh);
+    pkw = k == 1 ? o * pw[0] : vfma(o, pw[k - 1], pkw);
+    pkh = k == 1 ? o * ph[0] : vfma(o, ph[k - 1], pkh);
+    cumw = k == 1 ? m[k] * pw[0] : vfma(m[k], pw[k - 1], cumw);
+    cumh = k == 1 ? m[k] * ph[0] : vfma(m[k], ph[k - 1], cumh);
+    x0 = vfma(m[k], wp, x0);
+    y0 = vfma(m[k], hp, y0);
+    if (k == K - 1) { wp = sc.hi - px; hp = sc.hi - py; }   // last knot is exactly hi
+    else { wp = vfma(pw[k], splat<T>(sc.span_eff), splat<T>(sc.min_bin)); hp = vfma(ph[k], splat<T>(sc.span_eff), splat<T>(sc.min_bin)); }
+  }
+  bw = vfma(m[K - 1], wp, bw);
+  bh = vfma(m[K - 1], hp, bh);
+  pkw = vfma(m[K - 1], pw[K - 1], pkw);
+  pkh = vfma(m[K - 1], ph[K - 1], pkh);
+  kk = m[1];
+#pragma unroll
+  for (int k = 2; k < K; ++k) kk += m[k];
+  v2f ta, tbv;                                              // (t_k, t_k+1) of sample a, of sample b
+  slopes((int)kk.x, (int)kk.y, ta, tbv);
+  // natural units; the product is ROUNDED before |.| (see cond_spline_masked).  One exponential serves the softplus
+  // and its derivative: e = exp(-|n|), d = relu(n) + log1p(e) + min_slope, sigmoid(n) = (n >= 0 ? 1 : e) / (1 + e)
+  T n0 = v2f{ta.x, tbv.x} * LN2, n1 = v2f{ta.y, tbv.y} * LN2;
+  asm volatile("" : "+v"(n0), "+v"(n1));
+  T d0, d1, sg0, sg1;
+  {
+    const T a0 = vabs(n0), a1 = vabs(n1);
+    const T e0 = M::exp(-a0), e1 = M::exp(-a1);
+    const T ope0 = e0 + 1.0f, ope1 = e1 + 1.0f;
+    const T l0 = vsel(vlt(e0, 1e-4f), vfma(e0 * -0.5f, e0, e0), M::log(ope0));
+    const T l1 = vsel(vlt(e1, 1e-4f), vfma(e1 * -0.5f, e1, e1), M::log(ope1));
+    d0 = vfma(n0 + a0, splat<T>(0.5f), l0) + sc.min_slope;
+    d1 = vfma(n1 + a1, splat<T>(0.5f), l1) + sc.min_slope;
+    const T i0 = M::rcp(ope0), i1 = M::rcp(ope1);
+    sg0 = vsel(vge(n0, 0.0f), i0, e0 * i0);
+    sg1 = vsel(vge(n1, 0.0f), i1, e1 * i1);
+  }
+  const BinPartials2 p = rqs_partials_dir<INV, FAST>(v, x0, y0, bw, bh, d0, d1, sc.lo, sc.hi);
+  const BinAdjoint2 a = bin_adjoint<INV, FAST>(p, o_bar, l_bar);
+  // widths: w_j = span p_j + min_bin, x0 = lo + sum_{j<k} w_j, bw = w_k:  theta_bar_j = span p_j (wbar_j - sum_i wbar_i p_i)
+  const T Sw = vfma(a.x0, cumw, a.bw * pkw), Sh = vfma(a.y0, cumh, a.bh * pkh);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const T o = m[j] - m[j + 1];
+    const T wb = vfma(m[j + 1], a.x0, vfma(o, a.bw, -Sw));
+    const T hb = vfma(m[j + 1], a.y0, vfma(o, a.bh, -Sh));
+    tb[j] = pw[j] * sc.span_eff * wb;
+    tb[K + j] = ph[j] * sc.span_eff * hb;
+  }
+  sb0 = a.d0 * sg0; sb1 = a.d1 * sg1;
+  return a.v;
+}
+
+// ---------------------------------------------------------------------------
 // Conditioner forward that keeps the hidden activations (M = 2, H = P = 16).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void conditioner_keep(uniform_ptr w, int d, float c, const float* col, int first_idx,

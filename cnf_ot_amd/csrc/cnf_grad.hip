@@ -705,7 +705,7 @@ __global__ __launch_bounds__(GTS_MAX, 2) void vjp_kernel(const VjpArgs a) {
 // the forward through the tables, the spline partials (cond_spline_bwd / table_spline_bwd as in the MLP kernels),
 // the input adjoint S . theta_bar from the row already in LDS, and 20 accumulations -- no MLP recompute and no
 // per-sample GEMM.  pwl_stats_finish_kernel turns the statistics into gradient slabs, once per piece.
-//   vjp_pwl_kernel: one sample per lane, 1024 threads; LDS = `first` table | L tables (PWL_LROWS-row window) |
+//   vjp_pwl_kernel: two samples per lane (packed arithmetic), 512 threads; LDS = `first` table | L tables (PWL_LROWS-row window) |
 //   64-bit fixed-point accumulators [L][64 pieces][33] (A | B per piece).
 // ---------------------------------------------------------------------------
 constexpr int PWL_STAT = 2 * PWL_P;                 // statistics per piece: A[16] | B[16]
@@ -723,6 +723,11 @@ typedef unsigned long long stat_t;
 constexpr int PWL_STAT_LDS = PWL_STAT + 1;
 constexpr int PWL_ACC_W = 64;
 constexpr int PWL_STAT_SLICES = 64;                 // slices per chunk of the table backward (statistics buffer)
+// Lanes of a wave that land in the same piece add to the same addresses, and the LDS serialises them: the accumulators
+// exist up to PWL_ACC_R times (as many as fit in LDS next to the L tables: 3 at L = 2, 1 from L = 3 on), lane t uses
+// copy t mod acc_r (summed when a slice's statistics are flushed).  Measured at L = 2, one pass over 4.2 M points:
+// 1 copy 0.34-0.39 ms, 3 copies 0.28-0.33 (scripts/exp_vjp_tables_only.py).
+constexpr int PWL_ACC_R = 3;
 
 // 2^(28 - e) for the largest adjoint magnitude 2^e <= |x| < 2^(e+1) (bits of |x| as given by adjoint_max_kernel);
 // all-zero adjoints: any scale will do
@@ -778,22 +783,28 @@ struct VjpPwlArgs {
   int64_t n_params;      // per-bin adjoint sums (one owner per slab: a fixed summation order)
   int64_t B, slice_len;
   int32_t n_slices, tiles_per_slice;
+  int32_t acc_r;         // copies of the LDS accumulators (1 .. PWL_ACC_R)
 };
 
+constexpr int VJP_PWL_THREADS = 512;      // two samples per lane: tiles of 1 024 samples
+
 template <bool TO_BASE>
-__global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
+__global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlArgs a) {
   constexpr int K = GK, WIN = PWL_LROWS;
   constexpr bool INV = !TO_BASE;
   constexpr int MAXL = 4;
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   constexpr int HDR = (hdr_floats(K) + 3) & ~3;
-  const int L = a.m.L, NT = blockDim.x, tid = threadIdx.x;
+  const int L = a.m.L, NT = blockDim.x, tid = threadIdx.x, TS = 2 * NT;
   float* tab = lds_raw;
   float* tbl = lds_raw + HDR;
   stat_t* acc = reinterpret_cast<stat_t*>(tbl + L * pwl_ltbl(WIN));      // [L][PWL_ACC_W][PWL_STAT_LDS] (8-byte aligned: HDR, pwl_ltbl even)
-  float* red = reinterpret_cast<float*>(acc + L * PWL_ACC_W * PWL_STAT_LDS);      // [waves][GP]
+  const int acc_n = L * PWL_ACC_W * PWL_STAT_LDS;                          // one copy
+  const int acc_r = a.acc_r;
+  float* red = reinterpret_cast<float*>(acc + acc_r * acc_n);              // [waves][GP]
   for (int i = tid; i < hdr_floats(K); i += NT) tab[i] = a.m.prep[i];
-  for (int i = tid; i < L * PWL_ACC_W * PWL_STAT_LDS; i += NT) acc[i] = 0;
+  for (int i = tid; i < acc_r * acc_n; i += NT) acc[i] = 0;
+  stat_t* acc_mine = acc + (tid % acc_r) * acc_n;
   const SplineConsts sc = sc_scalars(a.m.sc);
   // fixed-point scale 2^(28 - e), e = the exponent of the largest adjoint; x -> round(x scale) by the 1.5 2^52 trick
   const double fx_scale = SliceSum::uniform(stat_scale(*a.amax));      // (wave-uniform: a scalar register pair)
@@ -810,7 +821,7 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
       const stat_t q = to_fixed(xs);
       if (p < PWL_ACC_W) {
         typedef stat_t __attribute__((address_space(3))) * lds_q_ptr;
-        lds_q_ptr d3 = (lds_q_ptr)(uintptr_t)(uint32_t)(uintptr_t)(acc + (l * PWL_ACC_W + p) * PWL_STAT_LDS + e);
+        lds_q_ptr d3 = (lds_q_ptr)(uintptr_t)(uint32_t)(uintptr_t)(acc_mine + (l * PWL_ACC_W + p) * PWL_STAT_LDS + e);
         __hip_atomic_fetch_add(d3, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else {
         atomicAdd(a.stats + (((int64_t)slice * L + l) * PWL_NPIECE + p) * PWL_STAT + e, q);
@@ -819,11 +830,54 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
       atomicAdd(a.coarse + (((int64_t)slice * L + l) * PWL_NPIECE + p) * PWL_STAT + e, to_fixed(xs * 2.3283064365386963e-10));
     }                                                         // (beyond: not representable in float32 sums either)
   };
-  FirstAcc fa;
+  // One sample's theta_bar into the statistics of its piece.  The adjoints of a softmax group's logits sum to zero: the
+  // last width and the last height entry are not accumulated (pwl_stats_finish_kernel restores them as minus the sum
+  // of the other four) -- 20 atomic instructions per sample and layer.  One range test decides between the
+  // straight-line form (every term within the fine scale, the piece's accumulators in LDS) and the general one.
+  auto add_stats = [&](int slice, int l, int p, float du, const float (&t)[2 * K], int kk, float sb0, float sb1) {
+    float big = fmaxf(fabsf(sb0), fabsf(sb1));
 #pragma unroll
-  for (int j = 0; j < GK; ++j) { fa.Wb[j] = 0.0f; fa.Hb[j] = 0.0f; }
+    for (int m2 = 0; m2 < 2 * K; ++m2) big = fmaxf(big, fabsf(t[m2]));
+    big *= fmaxf(1.0f, fabsf(du));
+    // (fmaxf drops NaNs: the sum of the terms does not) a non-finite term poisons the call's gradient, like the
+    // float accumulation of the MLP backward would -- the fixed-point sums cannot carry it themselves
+    float chk = (sb0 + sb1) * du;
 #pragma unroll
-  for (int j = 0; j <= GK; ++j) fa.Db[j] = 0.0f;
+    for (int m2 = 0; m2 < 2 * K; ++m2) chk += t[m2];
+    if (!(fabsf(chk) < INFINITY) || !(big < INFINITY)) {
+      atomicOr(a.amax + 1, 1u);
+    } else if (p < PWL_ACC_W && (double)big * fx_scale < 1125899906842624.0) {
+      typedef stat_t __attribute__((address_space(3))) * lds_q_ptr;
+      lds_q_ptr d3 = (lds_q_ptr)(uintptr_t)(uint32_t)(uintptr_t)(acc_mine + (l * PWL_ACC_W + p) * PWL_STAT_LDS);
+      auto add = [&](lds_q_ptr d, float x) {
+        const double dd = fma((double)x, fx_scale, 6755399441055744.0);
+        __hip_atomic_fetch_add(d, (stat_t)(__double_as_longlong(dd) - __double_as_longlong(6755399441055744.0)),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      };
+      // odd lanes add their B entry where even lanes add their A entry: lanes of one piece meet on two addresses per
+      // instruction instead of one
+      const bool sw = tid & 1;
+      const float f0 = sw ? du : 1.0f, f1 = sw ? 1.0f : du;
+      const lds_q_ptr q0 = d3 + (sw ? PWL_P : 0), q1 = d3 + (sw ? 0 : PWL_P);
+#pragma unroll
+      for (int m2 = 0; m2 < 2 * K; ++m2)
+        if (m2 % K != K - 1) { add(q0 + m2, f0 * t[m2]); add(q1 + m2, f1 * t[m2]); }
+      add(q0 + 2 * K + kk, f0 * sb0);     add(q1 + 2 * K + kk, f1 * sb0);
+      add(q0 + 2 * K + kk + 1, f0 * sb1); add(q1 + 2 * K + kk + 1, f1 * sb1);
+    } else {
+#pragma unroll
+      for (int m2 = 0; m2 < 2 * K; ++m2)
+        if (m2 % K != K - 1) { accumulate(slice, l, p, m2, t[m2]); accumulate(slice, l, p, PWL_P + m2, du * t[m2]); }
+      accumulate(slice, l, p, 2 * K + kk, sb0);     accumulate(slice, l, p, PWL_P + 2 * K + kk, du * sb0);
+      accumulate(slice, l, p, 2 * K + kk + 1, sb1); accumulate(slice, l, p, PWL_P + 2 * K + kk + 1, du * sb1);
+    }
+  };
+  // the `first` spline's per-bin adjoint sums of the lane's samples (pair-wide; folded at the end)
+  v2f Wb[K], Hb[K], Db[K + 1];
+#pragma unroll
+  for (int j = 0; j < K; ++j) { Wb[j] = splat<v2f>(0.0f); Hb[j] = splat<v2f>(0.0f); }
+#pragma unroll
+  for (int j = 0; j <= K; ++j) Db[j] = splat<v2f>(0.0f);
 
   auto flush = [&](int slice) {          // LDS accumulators -> the slice's statistics, and clear
     __syncthreads();
@@ -832,8 +886,9 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
       const int lp = i / PWL_STAT, m2 = i - lp * PWL_STAT;            // (layer, piece), entry
       const int l = lp / PWL_ACC_W, p = lp - l * PWL_ACC_W;
       stat_t* e = acc + lp * PWL_STAT_LDS + m2;
-      const stat_t v = *e;
-      if (v != 0) { atomicAdd(g + ((int64_t)l * PWL_NPIECE + p) * PWL_STAT + m2, v); *e = 0; }
+      stat_t v = 0;
+      for (int r = 0; r < acc_r; ++r) { v += e[r * acc_n]; e[r * acc_n] = 0; }
+      if (v != 0) atomicAdd(g + ((int64_t)l * PWL_NPIECE + p) * PWL_STAT + m2, v);
     }
     __syncthreads();
   };
@@ -853,44 +908,54 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
     }
     const int64_t s0 = (int64_t)slice * a.slice_len;
     const int64_t len = a.B - s0 < a.slice_len ? a.B - s0 : a.slice_len;
-    const int64_t j = (int64_t)(tile - slice * a.tiles_per_slice) * NT + tid;
+    const int64_t j = (int64_t)(tile - slice * a.tiles_per_slice) * TS + 2 * tid;      // the lane's samples: j, j + 1
     const int64_t g = s0 + j;
-    const bool valid = j < len;
-    float u[2] = {0.0f, 0.0f}, ob[2] = {0.0f, 0.0f};
-    float ld_bar = 0.0f;
-    if (valid) {
-      const v2f x = *reinterpret_cast<const v2f*>(a.pts + 2 * g);
-      u[0] = x.x; u[1] = x.y;
-      if (a.ybar) { const v2f y = *reinterpret_cast<const v2f*>(a.ybar + 2 * g); ob[0] = y.x; ob[1] = y.y; }
-      if (a.ldbar) ld_bar = a.ldbar[g];
+    const bool v0 = j < len, v1 = j + 1 < len;
+    f4 x = {0.f, 0.f, 0.f, 0.f}, yb = {0.f, 0.f, 0.f, 0.f};
+    v2f ld_bar = {0.f, 0.f};
+    if (v1) {
+      x = *reinterpret_cast<const f4*>(a.pts + 2 * g);
+      if (a.ybar) yb = *reinterpret_cast<const f4*>(a.ybar + 2 * g);
+      if (a.ldbar) ld_bar = *reinterpret_cast<const v2f*>(a.ldbar + g);
+    } else if (v0) {
+      x[0] = a.pts[2 * g]; x[1] = a.pts[2 * g + 1];
+      if (a.ybar) { yb[0] = a.ybar[2 * g]; yb[1] = a.ybar[2 * g + 1]; }
+      if (a.ldbar) ld_bar.x = a.ldbar[g];
     }
+    v2f u0 = {x[0], x[2]}, u1 = {x[1], x[3]};
+    v2f ob0 = {yb[0], yb[2]}, ob1 = {yb[1], yb[3]};
     const float* gtbl = a.tables + (int64_t)slice * L * PWL_TBL;
-    // ---- forward through the tables, keeping every layer's inputs and outputs
-    float in_f[MAXL], in_o[MAXL], out_f[MAXL];
+    // ---- forward through the tables, keeping every layer's inputs and outputs (flow2_tables' calls)
+    v2f in_f[MAXL], in_o[MAXL], out_f[MAXL];
 #pragma unroll
     for (int step = 0; step < MAXL; ++step) {
       if (step < L) {
         const int l = TO_BASE ? L - 1 - step : step;
         const bool odd = l & 1;
-        const float uf = odd ? u[1] : u[0], uo = odd ? u[0] : u[1];
-        float of, oo = 0.0f, ld;
-        table_spline<K, INV, true, float>(tab, uf, sc, of, ld);
+        const v2f uf = odd ? u1 : u0, uo = odd ? u0 : u1;
+        v2f of, oo = splat<v2f>(0.0f), ld;
+        table_spline<K, INV, true, v2f>(tab, uf, sc, of, ld);
         // The backward never reads a layer's conditioned OUTPUT: data -> base takes the spline partials at the layer's
-        // input (cond_spline_bwd<INV = false>), base -> data at the output, which cond_spline_bwd forms itself in the
-        // bin it selects (consistent with its own knots; see pass_bwd).  So the last layer's table lookup, softmax and
-        // spline -- whose result nothing downstream reads -- are skipped here
+        // input, base -> data at the output, which cond_spline_bwd_rows forms itself in the bin it selects.  So the last
+        // layer's table lookup, softmax and spline -- whose result nothing downstream reads -- are skipped here
         if (step != L - 1) {
-          float th[PWL_P];
+          const float* tl = tbl + l * pwl_ltbl(WIN);
+          const float* gl = gtbl + (int64_t)l * PWL_TBL;
+          const v2f uc = TO_BASE ? of : uf;
+          PwlRows rr;
           bool general;
-          pwl_eval<WIN>(tbl + l * pwl_ltbl(WIN), gtbl + (int64_t)l * PWL_TBL, TO_BASE ? of : uf, th, general);
-#pragma unroll
-          for (int m2 = 0; m2 < 2 * K; ++m2) th[m2] *= LN2;                        // table rows: log2 units ...
-#pragma unroll
-          for (int m2 = 2 * K; m2 < PWL_P; ++m2) th[m2] = fmaf(th[m2], LN2, -sc.sp_offset);   // ... slopes with the offset added
-          cond_spline<K, INV, true, float>(th, uo, sc, oo, ld);
+          v2f qa[K], qb[K];
+          pwl_find<WIN>(tl, uc, rr, general);
+          rr.dua = pwl_logit_pairs<WIN>(rr.ra, gl, rr.pa, uc.x, qa);
+          rr.dub = pwl_logit_pairs<WIN>(rr.rb, gl, rr.pb, uc.y, qb);
+          auto slopes = [&](int ka, int kb, v2f& ta, v2f& tb) {
+            ta = pwl_slope_pair<WIN>(rr.ra, gl, rr.pa, ka, rr.dua);
+            tb = pwl_slope_pair<WIN>(rr.rb, gl, rr.pb, kb, rr.dub);
+          };
+          cond_spline_rows<K, INV, true, false, false>(qa, qb, slopes, uo, sc, oo, ld);
         }
         in_f[step] = uf; in_o[step] = uo; out_f[step] = of;
-        u[odd ? 1 : 0] = of; u[odd ? 0 : 1] = oo;
+        u0 = odd ? oo : of; u1 = odd ? of : oo;
       }
     }
     // ---- backward
@@ -899,88 +964,53 @@ __global__ __launch_bounds__(1024) void vjp_pwl_kernel(const VjpPwlArgs a) {
       if (step < L) {
         const int l = TO_BASE ? L - 1 - step : step;
         const bool odd = l & 1;
-        float ob_f = odd ? ob[1] : ob[0];
-        const float ob_o = odd ? ob[0] : ob[1];
+        v2f ob_f = odd ? ob1 : ob0;
+        const v2f ob_o = odd ? ob0 : ob1;
         const float* tl = tbl + l * pwl_ltbl(WIN);
         const float* gl = gtbl + (int64_t)l * PWL_TBL;
-        const float ucond = TO_BASE ? out_f[step] : in_f[step];
+        const v2f uc = TO_BASE ? out_f[step] : in_f[step];
+        PwlRows rr;
         bool general;
-        const int p = pwl_piece(tl, ucond, general);
-        const float du = ucond - tl[PWL_OFF_REF + p];
-        // the piece's slopes S and intercepts: theta (natural units) and d theta / d u
-        float S[PWL_P], th[PWL_P];
-        {
-          const float* row = p < WIN ? tl + PWL_OFF_PIECE + p * PWL_ROW : gl + PWL_OFF_PIECE + p * PWL_ROW;
-#pragma unroll
-          for (int m2 = 0; m2 < PWL_P; ++m2) {
-            S[m2] = row[m2] * LN2;
-            th[m2] = fmaf(row[m2], du, row[PWL_P + m2]) * LN2 - (m2 >= 2 * K ? sc.sp_offset : 0.0f);
-          }
-        }
+        v2f qa[K], qb[K];
+        pwl_find<WIN>(tl, uc, rr, general);
+        rr.dua = pwl_logit_pairs<WIN>(rr.ra, gl, rr.pa, uc.x, qa);
+        rr.dub = pwl_logit_pairs<WIN>(rr.rb, gl, rr.pb, uc.y, qb);
+        auto slopes = [&](int ka, int kb, v2f& ta, v2f& tb) {
+          ta = pwl_slope_pair<WIN>(rr.ra, gl, rr.pa, ka, rr.dua);
+          tb = pwl_slope_pair<WIN>(rr.rb, gl, rr.pb, kb, rr.dub);
+        };
         // theta_bar: the 2K softmax entries in tb, the two non-zero slope entries (knots kk, kk + 1 of the selected
-        // bin) apart -- their accumulators and their rows' slopes are addressed with kk instead of six predicated
-        // copies of everything
-        float tb[PWL_P];
-        int kk;
-        float sb0, sb1;
-        const float ub_o = cond_spline_bwd<K, INV, true, true>(th, in_o[step], 0.0f, ob_o, ld_bar, sc, tb, &kk, &sb0, &sb1, true);
-        const float* rowk = (p < WIN ? tl + PWL_OFF_PIECE + p * PWL_ROW : gl + PWL_OFF_PIECE + p * PWL_ROW) + 2 * K + kk;
-        float ucond_bar = fmaf(rowk[0] * LN2, sb0, rowk[1] * LN2 * sb1);
+        // bin) apart -- their accumulators and their rows' slopes are addressed with kk
+        v2f tb[2 * K], kkf, sb0, sb1;
+        const v2f ub_o = cond_spline_bwd_rows<K, INV, true>(qa, qb, slopes, in_o[step], ob_o, ld_bar, sc, tb, kkf, sb0, sb1);
+        const int kka = (int)kkf.x, kkb = (int)kkf.y;
+        float ta[2 * K], tc[2 * K];
 #pragma unroll
-        for (int m2 = 0; m2 < 2 * K; ++m2) ucond_bar = fmaf(S[m2], tb[m2], ucond_bar);
-        // The adjoints of a softmax group's logits sum to zero: the last width and the last height entry are not
-        // accumulated (pwl_stats_finish_kernel restores them as minus the sum of the other four) -- 20 atomic
-        // instructions per layer.  One range test per layer decides between the straight-line form (every term
-        // within the fine scale, the piece's accumulators in LDS) and the general one.
-        if (valid) {
-          float big = fmaxf(fabsf(sb0), fabsf(sb1));
-#pragma unroll
-          for (int m2 = 0; m2 < 2 * K; ++m2) big = fmaxf(big, fabsf(tb[m2]));
-          big *= fmaxf(1.0f, fabsf(du));
-          // (fmaxf drops NaNs: the sum of the terms does not) a non-finite term poisons the call's gradient, like the
-          // float accumulation of the MLP backward would -- the fixed-point sums cannot carry it themselves
-          float chk = (sb0 + sb1) * du;
-#pragma unroll
-          for (int m2 = 0; m2 < 2 * K; ++m2) chk += tb[m2];
-          if (!(fabsf(chk) < INFINITY) || !(big < INFINITY)) {
-            atomicOr(a.amax + 1, 1u);
-          } else if (p < PWL_ACC_W && (double)big * fx_scale < 1125899906842624.0) {
-            typedef stat_t __attribute__((address_space(3))) * lds_q_ptr;
-            lds_q_ptr d3 = (lds_q_ptr)(uintptr_t)(uint32_t)(uintptr_t)(acc + (l * PWL_ACC_W + p) * PWL_STAT_LDS);
-            auto add = [&](int e, float x) {
-              const double d = fma((double)x, fx_scale, 6755399441055744.0);
-              __hip_atomic_fetch_add(d3 + e, (stat_t)(__double_as_longlong(d) - __double_as_longlong(6755399441055744.0)),
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            };
-#pragma unroll
-            for (int m2 = 0; m2 < 2 * K; ++m2)
-              if (m2 % K != K - 1) { add(m2, tb[m2]); add(PWL_P + m2, du * tb[m2]); }
-            add(2 * K + kk, sb0);     add(PWL_P + 2 * K + kk, du * sb0);
-            add(2 * K + kk + 1, sb1); add(PWL_P + 2 * K + kk + 1, du * sb1);
-          } else {
-#pragma unroll
-            for (int m2 = 0; m2 < 2 * K; ++m2)
-              if (m2 % K != K - 1) { accumulate(slice, l, p, m2, tb[m2]); accumulate(slice, l, p, PWL_P + m2, du * tb[m2]); }
-            accumulate(slice, l, p, 2 * K + kk, sb0);     accumulate(slice, l, p, PWL_P + 2 * K + kk, du * sb0);
-            accumulate(slice, l, p, 2 * K + kk + 1, sb1); accumulate(slice, l, p, PWL_P + 2 * K + kk + 1, du * sb1);
-          }
-        }
-        float ub_f = 0.0f;
+        for (int m2 = 0; m2 < 2 * K; ++m2) { ta[m2] = tb[m2].x; tc[m2] = tb[m2].y; }
+        const v2f ucond_bar = v2f{pwl_row_dot<WIN>(rr.ra, gl, rr.pa, kka, ta, sb0.x, sb1.x),
+                                  pwl_row_dot<WIN>(rr.rb, gl, rr.pb, kkb, tc, sb0.y, sb1.y)};
+        v2f ub_f = splat<v2f>(0.0f);
         if (TO_BASE) ob_f += ucond_bar; else ub_f = ucond_bar;
-        ub_f += table_spline_bwd<K, INV, true>(tab, in_f[step], out_f[step], ob_f, ld_bar, sc, fa.Wb, fa.Hb, fa.Db);
-        ob[odd ? 1 : 0] = ub_f; ob[odd ? 0 : 1] = ub_o;
+        ub_f += table_spline_bwd<K, INV, true>(tab, in_f[step], ob_f, ld_bar, sc, Wb, Hb, Db);
+        // (last: LDS operations complete in order, a read issued behind the 40 accumulations would wait for all of them)
+        if (v0) add_stats(slice, l, rr.pa, rr.dua, ta, kka, sb0.x, sb1.x);
+        if (v1) add_stats(slice, l, rr.pb, rr.dub, tc, kkb, sb0.y, sb1.y);
+        ob0 = odd ? ub_o : ub_f; ob1 = odd ? ub_f : ub_o;
       }
     }
-    if (a.xbar && valid) *reinterpret_cast<v2f*>(a.xbar + 2 * g) = v2f{ob[0], ob[1]};
+    if (a.xbar) {
+      if (v1) *reinterpret_cast<f4*>(a.xbar + 2 * g) = f4{ob0.x, ob1.x, ob0.y, ob1.y};
+      else if (v0) { a.xbar[2 * g] = ob0.x; a.xbar[2 * g + 1] = ob1.x; }
+    }
   }
   if (cur >= 0) flush(cur);
-  // the `first` spline's per-bin adjoint sums: wave shuffle, block reduce, one atomic per entry and block
+  // the `first` spline's per-bin adjoint sums: wave shuffle, block reduce, one slab entry per block
   {
     float r[GP];
 #pragma unroll
-    for (int j = 0; j < GK; ++j) { r[j] = fa.Wb[j]; r[GK + j] = fa.Hb[j]; }
+    for (int j = 0; j < GK; ++j) { r[j] = Wb[j].x + Wb[j].y; r[GK + j] = Hb[j].x + Hb[j].y; }
 #pragma unroll
-    for (int j = 0; j <= GK; ++j) r[2 * GK + j] = fa.Db[j];
+    for (int j = 0; j <= GK; ++j) r[2 * GK + j] = Db[j].x + Db[j].y;
 #pragma unroll
     for (int j = 0; j < GP; ++j) {
 #pragma unroll
@@ -1648,15 +1678,21 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
   // 0.050 ms: ~0.06 ms of fixed cost -- table build, adjoint maximum, per-piece finishing -- against 0.12 us saved per
   // 1 000 points)
   if (m->use_pwl == 1 && (slice_len < 8192 || B < 524288)) return CNF_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(pts) & 7) || (reinterpret_cast<uintptr_t>(ybar) & 7) ||
-      (reinterpret_cast<uintptr_t>(xbar) & 7) || (n_slices > 1 && (slice_len & 1)))
+  // (a lane's two samples are one 16-byte access of the points and adjoints, one 8-byte access of ldbar)
+  if ((reinterpret_cast<uintptr_t>(pts) & 15) || (reinterpret_cast<uintptr_t>(ybar) & 15) ||
+      (reinterpret_cast<uintptr_t>(xbar) & 15) || (reinterpret_cast<uintptr_t>(ldbar) & 7) || (n_slices > 1 && (slice_len & 1)))
     return CNF_ERR_UNSUPPORTED;
-  const int threads = 1024;
-  const size_t lds = sizeof(float) * (size_t)(((hdr_floats(GK) + 3) & ~3) + L * pwl_ltbl(PWL_LROWS) +
-                                              2 * L * PWL_ACC_W * PWL_STAT_LDS + (threads / 64) * GP);
+  const int threads = VJP_PWL_THREADS, tile = 2 * threads;
+  auto lds_bytes = [&](int acc_r) {
+    return sizeof(float) * (size_t)(((hdr_floats(GK) + 3) & ~3) + L * pwl_ltbl(PWL_LROWS) +
+                                    2 * acc_r * L * PWL_ACC_W * PWL_STAT_LDS + (threads / 64) * GP);
+  };
+  int acc_r = PWL_ACC_R;
+  while (acc_r > 1 && lds_bytes(acc_r) > 160 * 1024) --acc_r;
+  const size_t lds = lds_bytes(acc_r);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
   if (to_base ? !ensure_lds(vjp_pwl_kernel<true>, lds) : !ensure_lds(vjp_pwl_kernel<false>, lds)) return CNF_ERR_UNSUPPORTED;
-  const int64_t tps = (slice_len + threads - 1) / threads;
+  const int64_t tps = (slice_len + tile - 1) / tile;
   for (int64_t s0 = 0; s0 < n_slices; s0 += PWL_STAT_SLICES) {
     const int64_t ns = n_slices - s0 < PWL_STAT_SLICES ? n_slices - s0 : PWL_STAT_SLICES;
     float* tables = nullptr;
@@ -1673,7 +1709,7 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     stat_t* coarse = stats + (size_t)PWL_STAT_SLICES * L * PWL_NPIECE * PWL_STAT;
     a.tables = tables; a.stats = stats; a.coarse = coarse; a.amax = amax; a.slabs = m->grad_slabs; a.n_params = m->n_params;
     a.B = (B - first) < ns * slice_len ? (B - first) : ns * slice_len;
-    a.slice_len = slice_len; a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps;
+    a.slice_len = slice_len; a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps; a.acc_r = acc_r;
     if (hipMemsetAsync(amax, 0, 8, stream) != hipSuccess) return CNF_ERR_HIP;
     hipLaunchKernelGGL(adjoint_max_kernel, dim3((unsigned)(m->num_cus * 2)), dim3(256), 0, stream, a.ybar, a.ybar ? 2 * a.B : 0, a.ldbar,
                        a.ldbar ? a.B : 0, amax);

@@ -243,6 +243,29 @@ __device__ __forceinline__ v2f pwl_slope_pair(lds_f_ptr row, const float* __rest
   return t;
 }
 
+// LN2 x (d theta / d u of piece p) . theta_bar for one sample: the 2K softmax entries `t` and the two slope entries
+// (s0, s1) at knots k, k + 1 -- the conditioner's input adjoint of the table backward (rows are in log2 units)
+template <int LROWS, int NT>
+__device__ __forceinline__ float pwl_row_dot(lds_f_ptr row, const float* __restrict__ gtbl, int p, int k,
+                                             const float (&t)[NT], float s0, float s1) {
+  static_assert(NT == 10, "K = 5");
+  auto dot = [&](f4 a, f4 b, v2f c, float k0, float k1) {
+    float r = k0 * s0;
+    r = fmaf(k1, s1, r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r = fmaf(a[e], t[e], r); r = fmaf(b[e], t[4 + e], r); }
+    r = fmaf(c.x, t[8], r);
+    return fmaf(c.y, t[9], r) * 0.693147182464599609375f;
+  };
+  const lds_f_ptr rk = row + k;
+  float r = dot(((lds_f4_ptr)row)[0], ((lds_f4_ptr)row)[1], ((lds_v2_ptr)row)[4], rk[10], rk[11]);
+  if (LROWS < PWL_NPIECE && p >= LROWS) {
+    const float* g = gtbl + PWL_OFF_PIECE + p * PWL_ROW;
+    r = dot(reinterpret_cast<const f4*>(g)[0], reinterpret_cast<const f4*>(g)[1], reinterpret_cast<const v2f*>(g)[4], g[10 + k], g[11 + k]);
+  }
+  return r;
+}
+
 // Stage the L tables of (set, slice) into LDS: header arrays + the rows in use, at most LROWS.
 template <int LROWS = PWL_LROWS>
 __device__ __forceinline__ void pwl_stage(float* tbl, const float* __restrict__ g0, int L, int tid, int nthreads) {
