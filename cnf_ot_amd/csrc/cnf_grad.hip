@@ -722,12 +722,17 @@ constexpr int PWL_STAT = 2 * PWL_P;                 // statistics per piece: A[1
 typedef unsigned long long stat_t;
 constexpr int PWL_STAT_LDS = PWL_STAT + 1;
 constexpr int PWL_ACC_W = 64;
-constexpr int PWL_STAT_SLICES = 64;                 // slices per chunk of the table backward (statistics buffer)
+constexpr int PWL_STAT_SLICES = 128;                // slices per chunk of the table backward (statistics buffer: 2 x 9.5 MB per flow layer)
 // Lanes of a wave that land in the same piece add to the same addresses, and the LDS serialises them: the accumulators
 // exist up to PWL_ACC_R times (as many as fit in LDS next to the L tables: 3 at L = 2, 1 from L = 3 on), lane t uses
 // copy t mod acc_r (summed when a slice's statistics are flushed).  Measured at L = 2, one pass over 4.2 M points:
 // 1 copy 0.34-0.39 ms, 3 copies 0.28-0.33 (scripts/exp_vjp_tables_only.py).
 constexpr int PWL_ACC_R = 3;
+// ... and what remains must not become a bank conflict instead: entry i of a piece sits in the 128-byte line slot
+// (p + i) mod 16, so copy r starts PWL_ACC_SKEW r entries late and the B entries are stored rotated by 8 -- the six
+// (copy, A | B) combinations of one piece and entry are six different slots.
+constexpr int PWL_ACC_SKEW = 5;
+__host__ __device__ constexpr int pwl_acc_entry(int e) { return e < PWL_P ? e : PWL_P + ((e - PWL_P + 8) & 15); }
 
 // 2^(28 - e) for the largest adjoint magnitude 2^e <= |x| < 2^(e+1) (bits of |x| as given by adjoint_max_kernel);
 // all-zero adjoints: any scale will do
@@ -748,7 +753,13 @@ __global__ __launch_bounds__(256) void adjoint_max_kernel(const float* __restric
     if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {            // 16-byte loads, four in flight per thread
       const f4* q = reinterpret_cast<const f4*>(p);
       const int64_t n4 = n >> 2;
-      for (int64_t i = t; i < n4; i += stride) { const f4 v = q[i]; take(v[0]); take(v[1]); take(v[2]); take(v[3]); }
+      int64_t i = t;
+      for (; i + 3 * stride < n4; i += 4 * stride) {             // (explicitly: the compiler kept one load per iteration)
+        const f4 v0 = q[i], v1 = q[i + stride], v2 = q[i + 2 * stride], v3 = q[i + 3 * stride];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { take(v0[e]); take(v1[e]); take(v2[e]); take(v3[e]); }
+      }
+      for (; i < n4; i += stride) { const f4 v = q[i]; take(v[0]); take(v[1]); take(v[2]); take(v[3]); }
       for (int64_t i = (n4 << 2) + t; i < n; i += stride) take(p[i]);
     } else {
       for (int64_t i = t; i < n; i += stride) take(p[i]);
@@ -801,10 +812,10 @@ __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlAr
   stat_t* acc = reinterpret_cast<stat_t*>(tbl + L * pwl_ltbl(WIN));      // [L][PWL_ACC_W][PWL_STAT_LDS] (8-byte aligned: HDR, pwl_ltbl even)
   const int acc_n = L * PWL_ACC_W * PWL_STAT_LDS;                          // one copy
   const int acc_r = a.acc_r;
-  float* red = reinterpret_cast<float*>(acc + acc_r * acc_n);              // [waves][GP]
+  float* red = reinterpret_cast<float*>(acc + acc_r * (acc_n + PWL_ACC_SKEW));      // [waves][GP]
   for (int i = tid; i < hdr_floats(K); i += NT) tab[i] = a.m.prep[i];
-  for (int i = tid; i < acc_r * acc_n; i += NT) acc[i] = 0;
-  stat_t* acc_mine = acc + (tid % acc_r) * acc_n;
+  for (int i = tid; i < acc_r * (acc_n + PWL_ACC_SKEW); i += NT) acc[i] = 0;
+  stat_t* acc_mine = acc + (tid % acc_r) * (acc_n + PWL_ACC_SKEW);
   const SplineConsts sc = sc_scalars(a.m.sc);
   // fixed-point scale 2^(28 - e), e = the exponent of the largest adjoint; x -> round(x scale) by the 1.5 2^52 trick
   const double fx_scale = SliceSum::uniform(stat_scale(*a.amax));      // (wave-uniform: a scalar register pair)
@@ -821,7 +832,7 @@ __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlAr
       const stat_t q = to_fixed(xs);
       if (p < PWL_ACC_W) {
         typedef stat_t __attribute__((address_space(3))) * lds_q_ptr;
-        lds_q_ptr d3 = (lds_q_ptr)(uintptr_t)(uint32_t)(uintptr_t)(acc_mine + (l * PWL_ACC_W + p) * PWL_STAT_LDS + e);
+        lds_q_ptr d3 = (lds_q_ptr)(uintptr_t)(uint32_t)(uintptr_t)(acc_mine + (l * PWL_ACC_W + p) * PWL_STAT_LDS + pwl_acc_entry(e));
         __hip_atomic_fetch_add(d3, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else {
         atomicAdd(a.stats + (((int64_t)slice * L + l) * PWL_NPIECE + p) * PWL_STAT + e, q);
@@ -858,12 +869,28 @@ __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlAr
       // instruction instead of one
       const bool sw = tid & 1;
       const float f0 = sw ? du : 1.0f, f1 = sw ? 1.0f : du;
-      const lds_q_ptr q0 = d3 + (sw ? PWL_P : 0), q1 = d3 + (sw ? 0 : PWL_P);
-#pragma unroll
-      for (int m2 = 0; m2 < 2 * K; ++m2)
-        if (m2 % K != K - 1) { add(q0 + m2, f0 * t[m2]); add(q1 + m2, f1 * t[m2]); }
-      add(q0 + 2 * K + kk, f0 * sb0);     add(q1 + 2 * K + kk, f1 * sb0);
-      add(q0 + 2 * K + kk + 1, f0 * sb1); add(q1 + 2 * K + kk + 1, f1 * sb1);
+      // (entry e of A at e, of B at pwl_acc_entry(16 + e) = 16 + (e + 8) mod 16: for the lane, B - A is +24 below e = 8, +8 from there)
+      static_assert(2 * K + K <= PWL_P && pwl_acc_entry(PWL_P + 8) == PWL_P, "slope entries 10 .. 15 do not wrap");
+      const lds_q_ptr qa = d3 + (sw ? PWL_P + 8 : 0), qb = d3 + (sw ? 0 : PWL_P + 8);      // entries 0 .. 7
+      const lds_q_ptr ra = d3 + (sw ? PWL_P - 8 : 0), rb = d3 + (sw ? 0 : PWL_P - 8);      // entries 8 .. 15
+      // ... and lanes 2, 3 (mod 4) take the entries of each pair (0,1) (2,3) (5,6) (7,8) (slopes) in the other order: twelve
+      // slots per piece and instruction pair.  A selected value, and the lane's address moved by one entry.
+      const bool sx = tid & 2;
+      const int up = sx ? 1 : 0;
+      auto add_pair = [&](lds_q_ptr a0, lds_q_ptr b0, int i, float x, float y) {      // x -> entry i, y -> entry i + 1
+        const float u0 = sx ? y : x, u1 = sx ? x : y;
+        add(a0 + i + up, f0 * u0);     add(b0 + i + up, f1 * u0);
+        add(a0 + i + 1 - up, f0 * u1); add(b0 + i + 1 - up, f1 * u1);
+      };
+      add_pair(qa, qb, 0, t[0], t[1]); add_pair(qa, qb, 2, t[2], t[3]);
+      add_pair(qa, qb, 5, t[5], t[6]);
+      // (entries 7 | 8 straddle the rotation of the B half)
+      {
+        const float u0 = sx ? t[8] : t[7], u1 = sx ? t[7] : t[8];
+        add((sx ? ra : qa) + 7 + up, f0 * u0);     add((sx ? rb : qb) + 7 + up, f1 * u0);
+        add((sx ? qa : ra) + 8 - up, f0 * u1);     add((sx ? qb : rb) + 8 - up, f1 * u1);
+      }
+      add_pair(ra, rb, 2 * K + kk, sb0, sb1);
     } else {
 #pragma unroll
       for (int m2 = 0; m2 < 2 * K; ++m2)
@@ -885,9 +912,9 @@ __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlAr
     for (int i = tid; i < L * PWL_ACC_W * PWL_STAT; i += NT) {
       const int lp = i / PWL_STAT, m2 = i - lp * PWL_STAT;            // (layer, piece), entry
       const int l = lp / PWL_ACC_W, p = lp - l * PWL_ACC_W;
-      stat_t* e = acc + lp * PWL_STAT_LDS + m2;
+      stat_t* e = acc + lp * PWL_STAT_LDS + pwl_acc_entry(m2);
       stat_t v = 0;
-      for (int r = 0; r < acc_r; ++r) { v += e[r * acc_n]; e[r * acc_n] = 0; }
+      for (int r = 0; r < acc_r; ++r) { v += e[r * (acc_n + PWL_ACC_SKEW)]; e[r * (acc_n + PWL_ACC_SKEW)] = 0; }
       if (v != 0) atomicAdd(g + ((int64_t)l * PWL_NPIECE + p) * PWL_STAT + m2, v);
     }
     __syncthreads();
@@ -1156,7 +1183,10 @@ __global__ __launch_bounds__(256) void pwl_stats_finish_kernel(const StatsFinish
 __global__ __launch_bounds__(1024) void grad_finish_kernel(const float* __restrict__ slabs, int64_t n_slabs,
                                                            int64_t n_params, const float* __restrict__ params,
                                                            float* __restrict__ grad, double span_eff,
-                                                           double sp_offset) {
+                                                           double sp_offset, uint32_t* clear2) {
+  // clear2: two words this launch leaves zero for the next call (the table backward's adjoint maximum and non-finite
+  // flag: every reader ran before this kernel on the same stream)
+  if (clear2 && blockIdx.x == 0 && threadIdx.x < 2) clear2[threadIdx.x] = 0;
   __shared__ float part[32][33];
   __shared__ double raw[GP];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -1601,7 +1631,7 @@ extern "C" int cnf_loss_terms_grad_multi(CnfModel* m, int32_t n_terms, const Cnf
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
   const int fb = (int)((m->n_params + 31) / 32);
   hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, n_slabs, m->n_params, params,
-                     grad, (double)m->sc.span_eff, (double)m->sc.sp_offset);
+                     grad, (double)m->sc.span_eff, (double)m->sc.sp_offset, (uint32_t*)nullptr);
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 
@@ -1685,7 +1715,7 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
   const int threads = VJP_PWL_THREADS, tile = 2 * threads;
   auto lds_bytes = [&](int acc_r) {
     return sizeof(float) * (size_t)(((hdr_floats(GK) + 3) & ~3) + L * pwl_ltbl(PWL_LROWS) +
-                                    2 * acc_r * L * PWL_ACC_W * PWL_STAT_LDS + (threads / 64) * GP);
+                                    2 * acc_r * (L * PWL_ACC_W * PWL_STAT_LDS + PWL_ACC_SKEW) + (threads / 64) * GP);
   };
   int acc_r = PWL_ACC_R;
   while (acc_r > 1 && lds_bytes(acc_r) > 160 * 1024) --acc_r;
@@ -1710,8 +1740,8 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     a.tables = tables; a.stats = stats; a.coarse = coarse; a.amax = amax; a.slabs = m->grad_slabs; a.n_params = m->n_params;
     a.B = (B - first) < ns * slice_len ? (B - first) : ns * slice_len;
     a.slice_len = slice_len; a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps; a.acc_r = acc_r;
-    if (hipMemsetAsync(amax, 0, 8, stream) != hipSuccess) return CNF_ERR_HIP;
-    hipLaunchKernelGGL(adjoint_max_kernel, dim3((unsigned)(m->num_cus * 2)), dim3(256), 0, stream, a.ybar, a.ybar ? 2 * a.B : 0, a.ldbar,
+    // (amax is zero on entry: cleared at allocation and by the grad_finish_kernel launch of the previous chunk or call)
+    hipLaunchKernelGGL(adjoint_max_kernel, dim3((unsigned)(m->num_cus * 4)), dim3(256), 0, stream, a.ybar, a.ybar ? 2 * a.B : 0, a.ldbar,
                        a.ldbar ? a.B : 0, amax);
     const int64_t tiles = ns * tps;
     const int64_t grid = tiles < m->num_cus ? tiles : m->num_cus;
@@ -1725,7 +1755,7 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     hipLaunchKernelGGL(pwl_stats_finish_kernel, dim3((unsigned)(ns * L)), dim3(256), 0, stream, f);
     const int fb = (int)((m->n_params + 31) / 32);
     hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, grid + ns * L, m->n_params,
-                       params, grad, (double)m->sc.span_eff, (double)m->sc.sp_offset);
+                       params, grad, (double)m->sc.span_eff, (double)m->sc.sp_offset, amax);
     if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
   }
   return CNF_OK;
@@ -1779,7 +1809,7 @@ static int pass_vjp_impl(CnfModel* m, int to_base, const float* pts, const float
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
   const int fb = (int)((m->n_params + 31) / 32);
   hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, n_slabs, m->n_params, params,
-                     grad, (double)m->sc.span_eff, (double)m->sc.sp_offset);
+                     grad, (double)m->sc.span_eff, (double)m->sc.sp_offset, (uint32_t*)nullptr);
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 
@@ -1831,7 +1861,7 @@ static int fd_vjp_launch(CnfModel* m, VjpArgs& a, const float* pts, const float*
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
   const int fb = (int)((m->n_params + 31) / 32);
   hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, n_slabs, m->n_params, params,
-                     grad, (double)m->sc.span_eff, (double)m->sc.sp_offset);
+                     grad, (double)m->sc.span_eff, (double)m->sc.sp_offset, (uint32_t*)nullptr);
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
 }
 

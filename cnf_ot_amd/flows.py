@@ -527,8 +527,8 @@ class FlowEngine:
           _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
         self._grad_enabled = True
       self._check_out(grad, (self.cfg.param_count(),), "grad")
-      if self._pwl_mode and B > 0:          # the table form of the backward builds tables for chunks of 64 slices
-        self.reserve(min(-(-B // c_block), 64))
+      if self._pwl_mode and B > 0:          # the table form of the backward builds tables for chunks of 128 slices
+        self.reserve(min(-(-B // c_block), 128))
     xbar = torch.empty_like(pts) if want_xbar else None
     if B > 0:
       with _OnDevice(self.device):
