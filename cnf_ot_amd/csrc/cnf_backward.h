@@ -382,7 +382,7 @@ template <int K> __device__ __forceinline__ void bin_masks_pairs(const float* kb
 // table_spline_bwd for a sample pair: returns the adjoint of the input, accumulates the pair's bin adjoints into the
 // lane's (pair-wide) per-bin sums
 template <int K, bool INV, bool FAST>
-__device__ __forceinline__ v2f table_spline_bwd(const float* tab, v2f v, v2f o_bar, v2f l_bar, const SplineConsts& sc,
+__device__ __forceinline__ v2f table_spline_bwd(const float* tab, v2f v, v2f o_bar, v2f l_bar, const SplineConsts sc,
                                                 v2f (&Wb)[K], v2f (&Hb)[K], v2f (&Db)[K + 1]) {
   v2f m[K + 1];
   bin_masks_pairs<K>(tab + tab_off(INV ? F_YKB : F_XKB, K), v, m);
@@ -412,7 +412,7 @@ __device__ __forceinline__ v2f table_spline_bwd(const float* tab, v2f v, v2f o_b
 // logits; returns the adjoint of the spline input.  INV: the output is formed here, in the bin selected here.
 template <int K, bool INV, bool FAST, class SlopeFetch>
 __device__ __forceinline__ v2f cond_spline_bwd_rows(const v2f (&qa)[K], const v2f (&qb)[K], SlopeFetch&& slopes, v2f v,
-                                                    v2f o_bar, v2f l_bar, const SplineConsts& sc, v2f (&tb)[2 * K],
+                                                    v2f o_bar, v2f l_bar, const SplineConsts sc, v2f (&tb)[2 * K],
                                                     v2f& kk, v2f& sb0, v2f& sb1) {
   using M = Math<FAST>;
   typedef v2f T;

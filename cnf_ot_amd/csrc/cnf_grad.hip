@@ -799,14 +799,17 @@ struct VjpPwlArgs {
 
 constexpr int VJP_PWL_THREADS = 512;      // two samples per lane: tiles of 1 024 samples
 
-template <bool TO_BASE>
+// LFIX > 0: the number of flow layers is this constant (the reference's 2): the layer loops are unrolled, the kept
+// inputs and outputs of the layers are registers with fixed names instead of arrays indexed by a loop counter
+// (which the compiler served from select chains and 16 bytes of scratch)
+template <bool TO_BASE, int LFIX = 0>
 __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlArgs a) {
   constexpr int K = GK, WIN = PWL_LROWS;
   constexpr bool INV = !TO_BASE;
-  constexpr int MAXL = 4;
+  constexpr int MAXL = LFIX ? LFIX : 4;
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   constexpr int HDR = (hdr_floats(K) + 3) & ~3;
-  const int L = a.m.L, NT = blockDim.x, tid = threadIdx.x, TS = 2 * NT;
+  const int L = LFIX ? LFIX : a.m.L, NT = blockDim.x, tid = threadIdx.x, TS = 2 * NT;
   float* tab = lds_raw;
   float* tbl = lds_raw + HDR;
   stat_t* acc = reinterpret_cast<stat_t*>(tbl + L * pwl_ltbl(WIN));      // [L][PWL_ACC_W][PWL_STAT_LDS] (8-byte aligned: HDR, pwl_ltbl even)
@@ -925,30 +928,48 @@ __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlAr
   const int t0 = blockIdx.x * per_block;
   const int t1 = t0 + per_block < total ? t0 + per_block : total;
   int cur = -1;
+  // A tile's points and adjoints are requested one tile ahead: issued where they are used, the loads' ~2 us were a
+  // third of a wave's time (rocprofv3 counters of round 3: 37 % of the wave cycles in s_waitcnt, 3 % of them on LDS)
+  struct TileIn { f4 x, yb; v2f ldb; };
+  auto tile_geom = [&](int tile, int& slice, int64_t& g, bool& v0, bool& v1) {
+    slice = tile / a.tiles_per_slice;
+    const int64_t s0 = (int64_t)slice * a.slice_len;
+    const int64_t len = a.B - s0 < a.slice_len ? a.B - s0 : a.slice_len;
+    const int64_t j = (int64_t)(tile - slice * a.tiles_per_slice) * TS + 2 * tid;      // the lane's samples: j, j + 1
+    g = s0 + j;
+    v0 = j < len; v1 = j + 1 < len;
+  };
+  auto tile_load = [&](int tile) {
+    TileIn t;
+    t.x = f4{0.f, 0.f, 0.f, 0.f}; t.yb = t.x; t.ldb = v2f{0.f, 0.f};
+    int slice; int64_t g; bool v0, v1;
+    tile_geom(tile, slice, g, v0, v1);
+    if (v1) {
+      t.x = *reinterpret_cast<const f4*>(a.pts + 2 * g);
+      if (a.ybar) t.yb = *reinterpret_cast<const f4*>(a.ybar + 2 * g);
+      if (a.ldbar) t.ldb = *reinterpret_cast<const v2f*>(a.ldbar + g);
+    } else if (v0) {
+      t.x[0] = a.pts[2 * g]; t.x[1] = a.pts[2 * g + 1];
+      if (a.ybar) { t.yb[0] = a.ybar[2 * g]; t.yb[1] = a.ybar[2 * g + 1]; }
+      if (a.ldbar) t.ldb.x = a.ldbar[g];
+    }
+    return t;
+  };
+  TileIn nxt;
+  if (t0 < t1) nxt = tile_load(t0);
   for (int tile = t0; tile < t1; ++tile) {
-    const int slice = tile / a.tiles_per_slice;
+    int slice; int64_t g; bool v0, v1;
+    tile_geom(tile, slice, g, v0, v1);
     if (slice != cur) {
       if (cur >= 0) flush(cur); else __syncthreads();
       pwl_stage<WIN>(tbl, a.tables + (int64_t)slice * L * PWL_TBL, L, tid, NT);
       cur = slice;
       __syncthreads();
     }
-    const int64_t s0 = (int64_t)slice * a.slice_len;
-    const int64_t len = a.B - s0 < a.slice_len ? a.B - s0 : a.slice_len;
-    const int64_t j = (int64_t)(tile - slice * a.tiles_per_slice) * TS + 2 * tid;      // the lane's samples: j, j + 1
-    const int64_t g = s0 + j;
-    const bool v0 = j < len, v1 = j + 1 < len;
-    f4 x = {0.f, 0.f, 0.f, 0.f}, yb = {0.f, 0.f, 0.f, 0.f};
-    v2f ld_bar = {0.f, 0.f};
-    if (v1) {
-      x = *reinterpret_cast<const f4*>(a.pts + 2 * g);
-      if (a.ybar) yb = *reinterpret_cast<const f4*>(a.ybar + 2 * g);
-      if (a.ldbar) ld_bar = *reinterpret_cast<const v2f*>(a.ldbar + g);
-    } else if (v0) {
-      x[0] = a.pts[2 * g]; x[1] = a.pts[2 * g + 1];
-      if (a.ybar) { yb[0] = a.ybar[2 * g]; yb[1] = a.ybar[2 * g + 1]; }
-      if (a.ldbar) ld_bar.x = a.ldbar[g];
-    }
+    const f4 x = nxt.x, yb = nxt.yb;
+    const v2f ld_bar = nxt.ldb;
+    if (tile + 1 < t1) nxt = tile_load(tile + 1);
+    __builtin_amdgcn_sched_barrier(0);
     v2f u0 = {x[0], x[2]}, u1 = {x[1], x[3]};
     v2f ob0 = {yb[0], yb[2]}, ob1 = {yb[1], yb[3]};
     const float* gtbl = a.tables + (int64_t)slice * L * PWL_TBL;
@@ -1721,7 +1742,9 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
   while (acc_r > 1 && lds_bytes(acc_r) > 160 * 1024) --acc_r;
   const size_t lds = lds_bytes(acc_r);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
-  if (to_base ? !ensure_lds(vjp_pwl_kernel<true>, lds) : !ensure_lds(vjp_pwl_kernel<false>, lds)) return CNF_ERR_UNSUPPORTED;
+  if (L == 2 ? (to_base ? !ensure_lds(vjp_pwl_kernel<true, 2>, lds) : !ensure_lds(vjp_pwl_kernel<false, 2>, lds))
+             : (to_base ? !ensure_lds(vjp_pwl_kernel<true>, lds) : !ensure_lds(vjp_pwl_kernel<false>, lds)))
+    return CNF_ERR_UNSUPPORTED;
   const int64_t tps = (slice_len + tile - 1) / tile;
   for (int64_t s0 = 0; s0 < n_slices; s0 += PWL_STAT_SLICES) {
     const int64_t ns = n_slices - s0 < PWL_STAT_SLICES ? n_slices - s0 : PWL_STAT_SLICES;
@@ -1746,8 +1769,13 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     const int64_t tiles = ns * tps;
     const int64_t grid = tiles < m->num_cus ? tiles : m->num_cus;
     if (grid + ns * L > m->grad_max_blocks * 4) return s0 == 0 ? CNF_ERR_UNSUPPORTED : CNF_ERR_HIP;      // (slabs: cnf_grad_enable)
-    if (to_base) hipLaunchKernelGGL(vjp_pwl_kernel<true>, dim3((unsigned)grid), dim3(threads), lds, stream, a);
-    else hipLaunchKernelGGL(vjp_pwl_kernel<false>, dim3((unsigned)grid), dim3(threads), lds, stream, a);
+    if (L == 2) {
+      if (to_base) hipLaunchKernelGGL((vjp_pwl_kernel<true, 2>), dim3((unsigned)grid), dim3(threads), lds, stream, a);
+      else hipLaunchKernelGGL((vjp_pwl_kernel<false, 2>), dim3((unsigned)grid), dim3(threads), lds, stream, a);
+    } else {
+      if (to_base) hipLaunchKernelGGL(vjp_pwl_kernel<true>, dim3((unsigned)grid), dim3(threads), lds, stream, a);
+      else hipLaunchKernelGGL(vjp_pwl_kernel<false>, dim3((unsigned)grid), dim3(threads), lds, stream, a);
+    }
     StatsFinishArgs f;
     f.weights = m->prep + hdr_floats(GK); f.per_layer = m->per_layer; f.cvals = c + s0; f.tables = tables;
     f.stats = stats; f.coarse = coarse; f.amax = amax; f.slabs = m->grad_slabs; f.n_params = m->n_params; f.L = L;
