@@ -77,6 +77,7 @@ SYMBOLS = {
   "cnf_loss_terms_grad_multi": (ctypes.c_int, [_P, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
   "cnf_input_vjp": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _I64, _P, _P, _P, _I64, _P]),
   "cnf_pass_vjp": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _P]),
+  "cnf_neg_logprob_vjp": (ctypes.c_int, [_P, _P, _P, _I64, ctypes.c_float, _P, _P, _P, _I64, _P]),
   "cnf_logprob_fd": (ctypes.c_int, [_P, _P, _P, _I64, ctypes.c_float, _P, _I64, _P]),
   "cnf_logprob_fd_vjp": (ctypes.c_int, [_P, _P, _P, _I64, ctypes.c_float, _P, _P, _P, _P, _I64, _P]),
   "cnf_score_fd_vjp": (ctypes.c_int, [_P, _P, _P, _I64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int32,

@@ -323,6 +323,10 @@ def _neg_logprob_tables(ctx, samples, cond, coef):
   """-sum log_prob(samples; cond) and its gradient: data -> base pass, log_prob = base(x) + ildj."""
   be = ctx.be
   c = be.slice_conds([cond])
+  # value and gradient from ONE launch over the data (cnf_neg_logprob_vjp: the backward kernel seeds itself)
+  total = be.neg_logprob_vjp(samples, c, coef, ctx.grad)
+  if total is not None:
+    return total
   # plain fp32 positions, like the fused loss kernel: a mean over the batch does not need the float64 position path
   # that makes single log_prob values good to 1e-5 (1.75 x the time of this launch)
   was = getattr(be, "_precise", True)

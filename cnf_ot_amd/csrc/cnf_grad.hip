@@ -795,6 +795,12 @@ struct VjpPwlArgs {
   int64_t B, slice_len;
   int32_t n_slices, tiles_per_slice;
   int32_t acc_r;         // copies of the LDS accumulators (1 .. PWL_ACC_R)
+  // SEED (cnf_neg_logprob_vjp): the output adjoints are formed in the kernel -- ybar = seed_coef * base point,
+  // ldbar = -seed_coef -- and sums[slice] receives sum -log_prob; amax_bits != 0: the scale's magnitude (no
+  // adjoint_max_kernel ran: the seeds are bounded by what the kernel itself produces)
+  float seed_coef;
+  double* sums;
+  uint32_t amax_bits;
 };
 
 constexpr int VJP_PWL_THREADS = 512;      // two samples per lane: tiles of 1 024 samples
@@ -802,8 +808,9 @@ constexpr int VJP_PWL_THREADS = 512;      // two samples per lane: tiles of 1 02
 // LFIX > 0: the number of flow layers is this constant (the reference's 2): the layer loops are unrolled, the kept
 // inputs and outputs of the layers are registers with fixed names instead of arrays indexed by a loop counter
 // (which the compiler served from select chains and 16 bytes of scratch)
-template <bool TO_BASE, int LFIX = 0>
+template <bool TO_BASE, int LFIX = 0, bool SEED = false>
 __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlArgs a) {
+  static_assert(!SEED || TO_BASE, "the density-fit term: data -> base");
   constexpr int K = GK, WIN = PWL_LROWS;
   constexpr bool INV = !TO_BASE;
   constexpr int MAXL = LFIX ? LFIX : 4;
@@ -821,7 +828,8 @@ __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlAr
   stat_t* acc_mine = acc + (tid % acc_r) * (acc_n + PWL_ACC_SKEW);
   const SplineConsts sc = sc_scalars(a.m.sc);
   // fixed-point scale 2^(28 - e), e = the exponent of the largest adjoint; x -> round(x scale) by the 1.5 2^52 trick
-  const double fx_scale = SliceSum::uniform(stat_scale(*a.amax));      // (wave-uniform: a scalar register pair)
+  const double fx_scale = SliceSum::uniform(stat_scale(a.amax_bits ? a.amax_bits : *a.amax));      // (wave-uniform: a scalar register pair)
+  [[maybe_unused]] SliceSum ssum;
   auto to_fixed = [&](double xs) -> stat_t {              // xs = x scale, |xs| < 2^50
     const double d = xs + 6755399441055744.0;
     return (stat_t)(__double_as_longlong(d) - __double_as_longlong(6755399441055744.0));
@@ -967,11 +975,12 @@ __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlAr
       __syncthreads();
     }
     const f4 x = nxt.x, yb = nxt.yb;
-    const v2f ld_bar = nxt.ldb;
+    v2f ld_bar = nxt.ldb;
     if (tile + 1 < t1) nxt = tile_load(tile + 1);
     __builtin_amdgcn_sched_barrier(0);
     v2f u0 = {x[0], x[2]}, u1 = {x[1], x[3]};
     v2f ob0 = {yb[0], yb[2]}, ob1 = {yb[1], yb[3]};
+    [[maybe_unused]] v2f lacc = splat<v2f>(0.0f);      // SEED: the pass's log|det J|
     const float* gtbl = a.tables + (int64_t)slice * L * PWL_TBL;
     // ---- forward through the tables, keeping every layer's inputs and outputs (flow2_tables' calls)
     v2f in_f[MAXL], in_o[MAXL], out_f[MAXL];
@@ -983,10 +992,11 @@ __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlAr
         const v2f uf = odd ? u1 : u0, uo = odd ? u0 : u1;
         v2f of, oo = splat<v2f>(0.0f), ld;
         table_spline<K, INV, true, v2f>(tab, uf, sc, of, ld);
+        if constexpr (SEED) lacc += ld;
         // The backward never reads a layer's conditioned OUTPUT: data -> base takes the spline partials at the layer's
         // input, base -> data at the output, which cond_spline_bwd_rows forms itself in the bin it selects.  So the last
         // layer's table lookup, softmax and spline -- whose result nothing downstream reads -- are skipped here
-        if (step != L - 1) {
+        if (SEED || step != L - 1) {      // (SEED: the term's value and seeds need the whole pass)
           const float* tl = tbl + l * pwl_ltbl(WIN);
           const float* gl = gtbl + (int64_t)l * PWL_TBL;
           const v2f uc = TO_BASE ? of : uf;
@@ -1001,10 +1011,22 @@ __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlAr
             tb = pwl_slope_pair<WIN>(rr.rb, gl, rr.pb, kb, rr.dub);
           };
           cond_spline_rows<K, INV, true, false, false>(qa, qb, slopes, uo, sc, oo, ld);
+          if constexpr (SEED) lacc += ld;
         }
         in_f[step] = uf; in_o[step] = uo; out_f[step] = of;
         u0 = odd ? oo : of; u1 = odd ? of : oo;
       }
+    }
+    if constexpr (SEED) {
+      // -log_prob = |x|^2 / 2 + log 2 pi - ildj at the recovered base point x; d(seed_coef * sum) / d(x, ildj)
+      const v2f nlp = vfma(u0, u0, u1 * u1) * 0.5f + (float)(2 * HALF_LOG_2PI) - lacc;
+      float part = (v0 ? nlp.x : 0.0f) + (v1 ? nlp.y : 0.0f);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+      ssum.add(a.sums, slice, part);
+      ob0 = v2f{v0 ? u0.x : 0.0f, v1 ? u0.y : 0.0f} * a.seed_coef;
+      ob1 = v2f{v0 ? u1.x : 0.0f, v1 ? u1.y : 0.0f} * a.seed_coef;
+      ld_bar = v2f{v0 ? -a.seed_coef : 0.0f, v1 ? -a.seed_coef : 0.0f};
     }
     // ---- backward
 #pragma unroll
@@ -1052,6 +1074,7 @@ __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlAr
     }
   }
   if (cur >= 0) flush(cur);
+  if constexpr (SEED) ssum.flush();
   // the `first` spline's per-bin adjoint sums: wave shuffle, block reduce, one slab entry per block
   {
     float r[GP];
@@ -1089,6 +1112,7 @@ struct StatsFinishArgs {
   stat_t* stats;
   stat_t* coarse;
   const uint32_t* amax;  // [0] largest adjoint, [1] non-finite flag
+  uint32_t amax_bits;    // != 0: in place of amax[0] (VjpPwlArgs)
   float* slabs;          // [first_slab + n_slices * L][n_params]
   int64_t n_params;
   int32_t L, first_slab;
@@ -1115,7 +1139,7 @@ __global__ __launch_bounds__(256) void pwl_stats_finish_kernel(const StatsFinish
   const float* T = a.tables + (int64_t)blockIdx.x * PWL_TBL;
   stat_t* st = a.stats + (int64_t)blockIdx.x * PWL_NPIECE * PWL_STAT;
   const int n = __float_as_int(T[PWL_N_SLOT]);
-  const double inv_scale = 1.0 / stat_scale(*a.amax);
+  const double inv_scale = 1.0 / stat_scale(a.amax_bits ? a.amax_bits : *a.amax);
   stat_t* sc2 = a.coarse + (int64_t)blockIdx.x * PWL_NPIECE * PWL_STAT;
   for (int i = tid; i < (n + 1) * PWL_STAT; i += blockDim.x) {
     const stat_t q = st[i], qc = sc2[i];
@@ -1714,9 +1738,11 @@ extern "C" int cnf_weighted_sum(const double* v, const double* w, int64_t n, dou
 // The table form of cnf_pass_vjp (vjp_pwl_kernel + pwl_stats_finish_kernel + grad_finish_kernel): dim 2, the
 // reference's network, a condition uniform over slices, tables reserved on the stream (cnf_model_reserve) for at
 // least min(n_slices, PWL_STAT_SLICES) slices.  CNF_ERR_UNSUPPORTED: the caller runs the MLP backward.
+// seed_sums != null: the density-fit form (cnf_neg_logprob_vjp) -- no adjoints come in, the kernel seeds itself with
+// seed_coef and writes the slices' sums of -log_prob.
 static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float* c, int64_t c_block,
                         const float* ybar, const float* ldbar, float* xbar, float* grad, const float* params,
-                        int64_t B, hipStream_t stream) {
+                        int64_t B, hipStream_t stream, float seed_coef = 0.0f, double* seed_sums = nullptr) {
   const CnfConfig& g = m->cfg;
   if (!m->use_pwl || !m->fast_math || !m->pwl_stats || g.dim != 2 || g.hidden_size != PWL_H || g.num_bins != GK ||
       g.mlp_num_layers != 2 || g.num_layers > 4 || g.periodized)
@@ -1742,9 +1768,20 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
   while (acc_r > 1 && lds_bytes(acc_r) > 160 * 1024) --acc_r;
   const size_t lds = lds_bytes(acc_r);
   if (lds > 160 * 1024) return CNF_ERR_UNSUPPORTED;
-  if (L == 2 ? (to_base ? !ensure_lds(vjp_pwl_kernel<true, 2>, lds) : !ensure_lds(vjp_pwl_kernel<false, 2>, lds))
-             : (to_base ? !ensure_lds(vjp_pwl_kernel<true>, lds) : !ensure_lds(vjp_pwl_kernel<false>, lds)))
+  const bool seeded = seed_sums != nullptr;
+  if (seeded ? (L == 2 ? !ensure_lds(vjp_pwl_kernel<true, 2, true>, lds) : !ensure_lds(vjp_pwl_kernel<true, 0, true>, lds))
+      : L == 2 ? (to_base ? !ensure_lds(vjp_pwl_kernel<true, 2>, lds) : !ensure_lds(vjp_pwl_kernel<false, 2>, lds))
+               : (to_base ? !ensure_lds(vjp_pwl_kernel<true>, lds) : !ensure_lds(vjp_pwl_kernel<false>, lds)))
     return CNF_ERR_UNSUPPORTED;
+  // The seeds are seed_coef x (a base point | 1): the scale is set for adjoints up to 32 |seed_coef| -- base points
+  // lie within the splines' range of +-10 unless the data does not -- with the 2^22 of head room every term has
+  uint32_t amax_bits = 0;
+  if (seeded) {
+    const float bound = 32.0f * fabsf(seed_coef);
+    union { float f; uint32_t u; } bits; bits.f = bound; amax_bits = bits.u;
+    if (!(bound < INFINITY)) return CNF_ERR_INVALID;
+    if (hipMemsetAsync(seed_sums, 0, sizeof(double) * (size_t)n_slices, stream) != hipSuccess) return CNF_ERR_HIP;
+  }
   const int64_t tps = (slice_len + tile - 1) / tile;
   for (int64_t s0 = 0; s0 < n_slices; s0 += PWL_STAT_SLICES) {
     const int64_t ns = n_slices - s0 < PWL_STAT_SLICES ? n_slices - s0 : PWL_STAT_SLICES;
@@ -1763,13 +1800,18 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     a.tables = tables; a.stats = stats; a.coarse = coarse; a.amax = amax; a.slabs = m->grad_slabs; a.n_params = m->n_params;
     a.B = (B - first) < ns * slice_len ? (B - first) : ns * slice_len;
     a.slice_len = slice_len; a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps; a.acc_r = acc_r;
+    a.seed_coef = seed_coef; a.sums = seeded ? seed_sums + s0 : nullptr; a.amax_bits = amax_bits;
     // (amax is zero on entry: cleared at allocation and by the grad_finish_kernel launch of the previous chunk or call)
-    hipLaunchKernelGGL(adjoint_max_kernel, dim3((unsigned)(m->num_cus * 4)), dim3(256), 0, stream, a.ybar, a.ybar ? 2 * a.B : 0, a.ldbar,
+    if (!seeded)
+      hipLaunchKernelGGL(adjoint_max_kernel, dim3((unsigned)(m->num_cus * 4)), dim3(256), 0, stream, a.ybar, a.ybar ? 2 * a.B : 0, a.ldbar,
                        a.ldbar ? a.B : 0, amax);
     const int64_t tiles = ns * tps;
     const int64_t grid = tiles < m->num_cus ? tiles : m->num_cus;
     if (grid + ns * L > m->grad_max_blocks * 4) return s0 == 0 ? CNF_ERR_UNSUPPORTED : CNF_ERR_HIP;      // (slabs: cnf_grad_enable)
-    if (L == 2) {
+    if (seeded) {
+      if (L == 2) hipLaunchKernelGGL((vjp_pwl_kernel<true, 2, true>), dim3((unsigned)grid), dim3(threads), lds, stream, a);
+      else hipLaunchKernelGGL((vjp_pwl_kernel<true, 0, true>), dim3((unsigned)grid), dim3(threads), lds, stream, a);
+    } else if (L == 2) {
       if (to_base) hipLaunchKernelGGL((vjp_pwl_kernel<true, 2>), dim3((unsigned)grid), dim3(threads), lds, stream, a);
       else hipLaunchKernelGGL((vjp_pwl_kernel<false, 2>), dim3((unsigned)grid), dim3(threads), lds, stream, a);
     } else {
@@ -1778,7 +1820,7 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     }
     StatsFinishArgs f;
     f.weights = m->prep + hdr_floats(GK); f.per_layer = m->per_layer; f.cvals = c + s0; f.tables = tables;
-    f.stats = stats; f.coarse = coarse; f.amax = amax; f.slabs = m->grad_slabs; f.n_params = m->n_params; f.L = L;
+    f.stats = stats; f.coarse = coarse; f.amax = amax; f.amax_bits = amax_bits; f.slabs = m->grad_slabs; f.n_params = m->n_params; f.L = L;
     f.first_slab = (int32_t)grid;
     hipLaunchKernelGGL(pwl_stats_finish_kernel, dim3((unsigned)(ns * L)), dim3(256), 0, stream, f);
     const int fb = (int)((m->n_params + 31) / 32);
@@ -1845,6 +1887,16 @@ extern "C" int cnf_input_vjp(CnfModel* m, int to_base, const float* pts, const f
                              const float* ybar, const float* ldbar, float* xbar, int64_t B, void* stream) {
   if (!xbar) return CNF_ERR_INVALID;
   return pass_vjp_impl(m, to_base, pts, c, c_block, ybar, ldbar, xbar, nullptr, nullptr, B, stream);
+}
+
+extern "C" int cnf_neg_logprob_vjp(CnfModel* m, const float* pts, const float* c, int64_t c_block, float loss_coef,
+                                   double* sums, float* grad, const float* params, int64_t B, void* stream) {
+  if (!m || !pts || !c || !sums || !grad || !params || B < 0 || c_block < 1) return CNF_ERR_INVALID;
+  if (!m->params_set || !m->grad_slabs) return CNF_ERR_INVALID;
+  if (!cnf_grad_supported(&m->cfg)) return CNF_ERR_UNSUPPORTED;
+  if (B == 0) return CNF_OK;
+  if (wait_for_params(m, (hipStream_t)stream) != CNF_OK) return CNF_ERR_HIP;
+  return pass_vjp_pwl(m, 1, pts, c, c_block, nullptr, nullptr, nullptr, grad, params, B, (hipStream_t)stream, loss_coef, sums);
 }
 
 extern "C" int cnf_pass_vjp(CnfModel* m, int to_base, const float* pts, const float* c, int64_t c_block,

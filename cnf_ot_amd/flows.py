@@ -541,6 +541,34 @@ class FlowEngine:
                                           _stream_ptr(self.device)), "cnf_pass_vjp")
     return xbar
 
+  def neg_logprob_vjp(self, pts, cond, loss_coef: float, grad, sums=None):
+    """cnf_neg_logprob_vjp: per-slice sums of -log_prob(pts; cond) (float64 device tensor) and, into `grad`,
+    loss_coef * d(their total) / d(params) -- one launch over the data.  Returns None where the table backward does not
+    apply (CNF_ERR_UNSUPPORTED): the caller composes the term from inverse_logdet + term_residual + pass_vjp."""
+    pts = self._points(pts, "neg_logprob_vjp")
+    B = pts.shape[0]
+    c, c_block = self.cond(cond, B)
+    if self._flat is None:
+      raise RuntimeError("load(params) before asking for gradients")
+    if not getattr(self, "_grad_enabled", False):
+      with _OnDevice(self.device):
+        _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
+      self._grad_enabled = True
+    self._check_out(grad, (self.cfg.param_count(),), "grad")
+    n_slices = max(-(-B // c_block), 1)
+    if sums is None:
+      sums = torch.empty(n_slices, dtype=torch.float64, device=self.device)
+    if not self._pwl_mode or B == 0:
+      return None
+    self.reserve(min(n_slices, 128))
+    with _OnDevice(self.device):
+      rc = self.lib.cnf_neg_logprob_vjp(self._h, pts.data_ptr(), c.data_ptr(), c_block, float(loss_coef), sums.data_ptr(),
+                                        grad.data_ptr(), self._flat.data_ptr(), B, _stream_ptr(self.device))
+    if rc == _capi.CNF_ERR_UNSUPPORTED:
+      return None
+    _capi.check(rc, "cnf_neg_logprob_vjp")
+    return sums
+
   def logprob_fd(self, pts, cond, dx: float) -> torch.Tensor:
     """cnf_logprob_fd: the central-difference score [B, D] of log_prob at pts."""
     pts = self._points(pts, "logprob_fd")

@@ -346,6 +346,18 @@ int cnf_pass_vjp(CnfModel *m, int to_base, const float *pts, const float *c,
                  float *xbar, float *grad, const float *params, int64_t B,
                  void *stream);
 
+/* Value and gradient of the density-fit term in ONE launch over the data (kl_loss_fn, applications.py:11-86, under
+ * jax.value_and_grad, solvers.py:94):
+ *   sums[s] = -sum_{i in slice s} log_prob(pts_i; c_s),   grad[p] += loss_coef * d(sum_s sums[s]) / dp
+ * -- the table form of cnf_pass_vjp in the data -> base direction with the output adjoints formed in the kernel
+ * (ybar = loss_coef * base point, ldbar = -loss_coef), so neither cnf_inverse_logdet nor cnf_term_residual nor the
+ * adjoint scan run, and the tables are built once.  Same conditions as the table form of cnf_pass_vjp;
+ * CNF_ERR_UNSUPPORTED where it does not apply: the caller composes the term from those three calls. */
+int cnf_neg_logprob_vjp(CnfModel *m, const float *pts, const float *c,
+                        int64_t c_block, float loss_coef, double *sums,
+                        float *grad, const float *params, int64_t B,
+                        void *stream);
+
 /* The score of the flow's density by central differences, the way the reference
  * forms it (kinetic_with_score_loss_fn / flow_matching_loss_fn,
  * applications.py:264-273; utils.py:366-381):

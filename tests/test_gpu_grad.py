@@ -579,8 +579,9 @@ def test_value_and_grad_through_the_table_backward(dev, subtype, monkeypatch):
   used = []
   monkeypatch.setattr(app, "TABLE_BACKWARD_MIN_SLICE", 256)
   monkeypatch.setattr(app, "TABLE_BACKWARD_MIN_POINTS", 256)
-  orig = be.pass_vjp
+  orig, orig_nlp = be.pass_vjp, be.neg_logprob_vjp
   monkeypatch.setattr(be, "pass_vjp", lambda *a, **k: (used.append(1), orig(*a, **k))[1])
+  monkeypatch.setattr(be, "neg_logprob_vjp", lambda *a, **k: (used.append(1), orig_nlp(*a, **k))[1])
   be.set_pwl(2)
   loss2, g2 = vg(params, 11, 50.0, B)
   torch.cuda.synchronize()
@@ -590,6 +591,45 @@ def test_value_and_grad_through_the_table_backward(dev, subtype, monkeypatch):
   eg = (g2.flat - g0.flat).abs().max().item() / g0.flat.abs().max().item()
   print(f"\n[ot {subtype}: table backward vs fused kernel] loss rel {el:.2e} grad rel {eg:.2e}")
   assert el <= 2e-5 and eg <= 2e-4
+
+
+@pytest.mark.parametrize("L", [2, 3])
+@pytest.mark.parametrize("S,Bs", [(1, 70001), (3, 9000), (5, 8194), (130, 1024)])
+def test_neg_logprob_vjp_equals_the_composed_term(dev, L, S, Bs):
+  """cnf_neg_logprob_vjp (kl_loss_fn under jax.value_and_grad, applications.py:11-86 / solvers.py:94: the table
+  backward seeding itself with ybar = coef x, ldbar = -coef) against the same term composed from cnf_inverse_logdet +
+  cnf_term_residual + cnf_pass_vjp: per-slice sums to 2e-6, gradient to 1e-5 of its largest entry.  Slices that end inside
+  a tile and inside a lane's sample pair, more slices than one chunk of statistics, a third flow layer."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params, _capi
+  cfg = FlowConfig(dim=2, num_layers=L)
+  params = Params.random(cfg, 0.2, seed=3, device=dev)
+  eng = FlowEngine(cfg, dev).load(params)
+  eng.set_pwl(2)
+  B = S * Bs
+  g = torch.Generator(device="cpu").manual_seed(S * 7 + Bs)
+  pts = (torch.randn(B, 2, generator=g) * 1.3).to(dev)
+  ts = torch.linspace(0.05, 0.95, S, device=dev)
+  coef = 0.013
+  g1 = torch.zeros(cfg.param_count(), device=dev)
+  sums1 = eng.neg_logprob_vjp(pts, ts, coef, g1)
+  assert sums1 is not None and eng.last_path() == "tables"
+  eng.set_precise(False)
+  x, ildj = eng.inverse_logdet(pts, ts)
+  eng.set_precise(True)
+  sums0, xbar, ldbar = eng.term_residual(_capi.TERM_NEG_LOGPROB, x, ildj, Bs, loss_coef=coef)
+  g0 = torch.zeros_like(g1)
+  eng.pass_vjp(pts, ts, xbar, ldbar, True, grad=g0, want_xbar=False)
+  torch.cuda.synchronize()
+  es = ((sums1 - sums0).abs() / sums0.abs()).max().item()
+  eg = (g1 - g0).abs().max().item() / g0.abs().max().item()
+  print(f"\n[neg_logprob_vjp L={L} {S} x {Bs}] sums rel {es:.2e} grad rel {eg:.2e}")
+  assert es <= 2e-6 and eg <= 1e-5
+  # accumulates into grad, and is bitwise reproducible
+  g2 = torch.zeros_like(g1)
+  sums2 = eng.neg_logprob_vjp(pts, ts, coef, g2)
+  torch.cuda.synchronize()
+  assert torch.equal(g2, g1)
+  torch.testing.assert_close(sums2, sums1, rtol=1e-12, atol=0)
 
 
 @pytest.mark.parametrize("D", [2, 3])
