@@ -1116,6 +1116,7 @@ struct StatsFinishArgs {
   float* slabs;          // [first_slab + n_slices * L][n_params]
   int64_t n_params;
   int32_t L, first_slab;
+  int32_t split;         // blocks per (slice, layer): block g of them takes the pieces of every split-th group of four
 };
 
 __global__ __launch_bounds__(256) void pwl_stats_finish_kernel(const StatsFinishArgs a) {
@@ -1127,7 +1128,9 @@ __global__ __launch_bounds__(256) void pwl_stats_finish_kernel(const StatsFinish
   __shared__ float scr[NWV][9 * H];                        // per wave: Bu | m1a | m1b | Pk | Qk | G2 | G2u | G1 | G1u
   __shared__ float part[NWV][NW];                          // the waves' partial results
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int slice = blockIdx.x / a.L, l = blockIdx.x % a.L;
+  // (few slices -- the density-fit term has one -- would leave the chip to ns x L workgroups walking 289 pieces each)
+  const int sl = blockIdx.x / a.split, gsub = blockIdx.x - sl * a.split;
+  const int slice = sl / a.L, l = sl % a.L;
   const float* w = a.weights + l * a.per_layer;
   const float c = a.cvals[slice];
   if (tid < H) {
@@ -1136,12 +1139,14 @@ __global__ __launch_bounds__(256) void pwl_stats_finish_kernel(const StatsFinish
     b1[tid] = w[3 * H + H * H + tid];
   }
   for (int i = tid; i < H * H; i += blockDim.x) { W1[i] = w[3 * H + i]; Wo[i] = w[3 * H + H * H + H + i]; }
-  const float* T = a.tables + (int64_t)blockIdx.x * PWL_TBL;
-  stat_t* st = a.stats + (int64_t)blockIdx.x * PWL_NPIECE * PWL_STAT;
+  const float* T = a.tables + (int64_t)sl * PWL_TBL;
+  stat_t* st = a.stats + (int64_t)sl * PWL_NPIECE * PWL_STAT;
   const int n = __float_as_int(T[PWL_N_SLOT]);
   const double inv_scale = 1.0 / stat_scale(a.amax_bits ? a.amax_bits : *a.amax);
-  stat_t* sc2 = a.coarse + (int64_t)blockIdx.x * PWL_NPIECE * PWL_STAT;
+  stat_t* sc2 = a.coarse + (int64_t)sl * PWL_NPIECE * PWL_STAT;
+  auto mine = [&](int p) { return (p / NWV) % a.split == gsub; };
   for (int i = tid; i < (n + 1) * PWL_STAT; i += blockDim.x) {
+    if (!mine(i / PWL_STAT)) continue;
     const stat_t q = st[i], qc = sc2[i];
     stat[i] = (float)(((double)(long long)q + (double)(long long)qc * 4294967296.0) * inv_scale);
     if (q != 0) st[i] = 0;                                 // cleared for the next call
@@ -1150,6 +1155,7 @@ __global__ __launch_bounds__(256) void pwl_stats_finish_kernel(const StatsFinish
   __syncthreads();
   // vjp_pwl_kernel leaves out the last logit of each softmax group (widths, heights): the group's adjoints sum to zero
   for (int i = tid; i < (n + 1) * 4; i += blockDim.x) {
+    if (!mine(i >> 2)) continue;
     float* g = stat + (i >> 2) * PWL_STAT + (i & 2 ? P : 0) + (i & 1 ? GK : 0);
     g[GK - 1] = -((g[0] + g[1]) + (g[2] + g[3]));
   }
@@ -1159,7 +1165,7 @@ __global__ __launch_bounds__(256) void pwl_stats_finish_kernel(const StatsFinish
   for (int q = 0; q < PER_LANE; ++q) out[q] = 0.0f;
   float* Bu = scr[wv], *m1a = Bu + H, *m1b = m1a + H, *Pk = m1b + H, *Qk = Pk + H, *G2 = Qk + H, *G2u = G2 + H,
         *G1 = G2u + H, *G1u = G1 + H;
-  for (int p = wv; p <= n; p += NWV) {                     // wave-uniform loop: no block barrier inside
+  for (int p = wv + NWV * gsub; p <= n; p += NWV * a.split) {      // wave-uniform loop: no block barrier inside
     const float* A = stat + p * PWL_STAT;
     const float sv = lane < PWL_STAT ? A[lane] : 0.0f;
     if (__builtin_amdgcn_ballot_w64(sv != 0.0f) == 0) continue;
@@ -1807,7 +1813,8 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
                        a.ldbar ? a.B : 0, amax);
     const int64_t tiles = ns * tps;
     const int64_t grid = tiles < m->num_cus ? tiles : m->num_cus;
-    if (grid + ns * L > m->grad_max_blocks * 4) return s0 == 0 ? CNF_ERR_UNSUPPORTED : CNF_ERR_HIP;      // (slabs: cnf_grad_enable)
+    const int split = ns * L <= 32 ? 8 : 1;
+    if (grid + ns * L * split > m->grad_max_blocks * 4) return s0 == 0 ? CNF_ERR_UNSUPPORTED : CNF_ERR_HIP;      // (slabs: cnf_grad_enable)
     if (seeded) {
       if (L == 2) hipLaunchKernelGGL((vjp_pwl_kernel<true, 2, true>), dim3((unsigned)grid), dim3(threads), lds, stream, a);
       else hipLaunchKernelGGL((vjp_pwl_kernel<true, 0, true>), dim3((unsigned)grid), dim3(threads), lds, stream, a);
@@ -1821,10 +1828,10 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     StatsFinishArgs f;
     f.weights = m->prep + hdr_floats(GK); f.per_layer = m->per_layer; f.cvals = c + s0; f.tables = tables;
     f.stats = stats; f.coarse = coarse; f.amax = amax; f.amax_bits = amax_bits; f.slabs = m->grad_slabs; f.n_params = m->n_params; f.L = L;
-    f.first_slab = (int32_t)grid;
-    hipLaunchKernelGGL(pwl_stats_finish_kernel, dim3((unsigned)(ns * L)), dim3(256), 0, stream, f);
+    f.first_slab = (int32_t)grid; f.split = split;
+    hipLaunchKernelGGL(pwl_stats_finish_kernel, dim3((unsigned)(ns * L * split)), dim3(256), 0, stream, f);
     const int fb = (int)((m->n_params + 31) / 32);
-    hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, grid + ns * L, m->n_params,
+    hipLaunchKernelGGL(grad_finish_kernel, dim3(fb), dim3(1024), 0, stream, m->grad_slabs, grid + ns * L * split, m->n_params,
                        params, grad, (double)m->sc.span_eff, (double)m->sc.sp_offset, amax);
     if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
   }
