@@ -413,22 +413,30 @@ __device__ __forceinline__ v2f table_spline_bwd(const float* tab, v2f v, v2f o_b
 template <int K, bool INV, bool FAST, class SlopeFetch>
 __device__ __forceinline__ v2f cond_spline_bwd_rows(const v2f (&qa)[K], const v2f (&qb)[K], SlopeFetch&& slopes, v2f v,
                                                     v2f o_bar, v2f l_bar, const SplineConsts sc, v2f (&tb)[2 * K],
-                                                    v2f& kk, v2f& sb0, v2f& sb1) {
+                                                    v2f& kk, v2f& sb0, v2f& sb1, bool shift_free = false) {
   using M = Math<FAST>;
   typedef v2f T;
   auto la = [&](int j) { return qa[j >> 1][j & 1]; };
   auto lb = [&](int j) { return qb[j >> 1][j & 1]; };
-  float mwa = la(0), mwb = lb(0), mha = la(K), mhb = lb(K);
-#pragma unroll
-  for (int k = 1; k < K; ++k) {
-    mwa = fmaxf(mwa, la(k)); mwb = fmaxf(mwb, lb(k));
-    mha = fmaxf(mha, la(K + k)); mhb = fmaxf(mhb, lb(K + k));
-  }
   T pw[K], ph[K];
+  if (shift_free) {      // (wave-uniform) the table builder has checked the samples' cells: each group's maximum within +-4 of 0
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    pw[k] = v2f{__builtin_amdgcn_exp2f(la(k) - mwa), __builtin_amdgcn_exp2f(lb(k) - mwb)};
-    ph[k] = v2f{__builtin_amdgcn_exp2f(la(K + k) - mha), __builtin_amdgcn_exp2f(lb(K + k) - mhb)};
+    for (int k = 0; k < K; ++k) {
+      pw[k] = v2f{__builtin_amdgcn_exp2f(la(k)), __builtin_amdgcn_exp2f(lb(k))};
+      ph[k] = v2f{__builtin_amdgcn_exp2f(la(K + k)), __builtin_amdgcn_exp2f(lb(K + k))};
+    }
+  } else {
+    float mwa = la(0), mwb = lb(0), mha = la(K), mhb = lb(K);
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+      mwa = fmaxf(mwa, la(k)); mwb = fmaxf(mwb, lb(k));
+      mha = fmaxf(mha, la(K + k)); mhb = fmaxf(mhb, lb(K + k));
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      pw[k] = v2f{__builtin_amdgcn_exp2f(la(k) - mwa), __builtin_amdgcn_exp2f(lb(k) - mwb)};
+      ph[k] = v2f{__builtin_amdgcn_exp2f(la(K + k) - mha), __builtin_amdgcn_exp2f(lb(K + k) - mhb)};
+    }
   }
   T sw = pw[0], sh = ph[0];
 #pragma unroll

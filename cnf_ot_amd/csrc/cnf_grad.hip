@@ -1052,7 +1052,8 @@ __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlAr
         // theta_bar: the 2K softmax entries in tb, the two non-zero slope entries (knots kk, kk + 1 of the selected
         // bin) apart -- their accumulators and their rows' slopes are addressed with kk
         v2f tb[2 * K], kkf, sb0, sb1;
-        const v2f ub_o = cond_spline_bwd_rows<K, INV, true>(qa, qb, slopes, in_o[step], ob_o, ld_bar, sc, tb, kkf, sb0, sb1);
+        const v2f ub_o = cond_spline_bwd_rows<K, INV, true>(qa, qb, slopes, in_o[step], ob_o, ld_bar, sc, tb, kkf, sb0, sb1,
+                                                            __builtin_amdgcn_ballot_w64(general) == 0);
         const int kka = (int)kkf.x, kkb = (int)kkf.y;
         float ta[2 * K], tc[2 * K];
 #pragma unroll
