@@ -78,6 +78,8 @@ SYMBOLS = {
   "cnf_input_vjp": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _I64, _P, _P, _P, _I64, _P]),
   "cnf_pass_vjp": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _P]),
   "cnf_neg_logprob_vjp": (ctypes.c_int, [_P, _P, _P, _I64, ctypes.c_float, _P, _P, _P, _I64, _P]),
+  "cnf_kinetic_potential_vjp": (ctypes.c_int, [_P, _P, _I64, _P, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_int32,
+                                               ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P, _P]),
   "cnf_logprob_fd": (ctypes.c_int, [_P, _P, _P, _I64, ctypes.c_float, _P, _I64, _P]),
   "cnf_logprob_fd_vjp": (ctypes.c_int, [_P, _P, _P, _I64, ctypes.c_float, _P, _P, _P, _P, _I64, _P]),
   "cnf_score_fd_vjp": (ctypes.c_int, [_P, _P, _P, _I64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int32,

@@ -348,6 +348,9 @@ def _kinetic_tables(ctx, z, conds, count, dt, coef):
   S = _n_conds(th)
   half = np.float32(0.5 * dt)
   c2 = be.slice_conds(_cat_conds([th - half, th + half]))
+  done = be.kinetic_potential_vjp(z, c2, S, dt, coef, ctx.grad) if hasattr(be, "kinetic_potential_vjp") else None
+  if done is not None:      # (one call: no repeated copy of z, one table build, no adjoint scan)
+    return done[0]
   z2 = z.repeat(2 * S, 1)
   r, _ = be.forward_logdet(z2, c2, want_logdet=False)
   sums, rbar, _ = be.term_residual(_capi.TERM_KINETIC, r, None, count, p0=dt, loss_coef=coef)
@@ -378,6 +381,10 @@ def _kinetic_potential_tables(ctx, z, conds, count, dt, c_kin, subtype, a, c_pot
   n = S * count
   half = np.float32(0.5 * dt)
   c3 = be.slice_conds(_cat_conds([th - half, th + half, th]))
+  done = (be.kinetic_potential_vjp(z, c3, S, dt, c_kin, ctx.grad, subtype=_capi.POTENTIALS[subtype], a=a, c_pot=c_pot)
+          if hasattr(be, "kinetic_potential_vjp") else None)
+  if done is not None:
+    return done
   z3 = z.repeat(3 * S, 1)
   r, _ = be.forward_logdet(z3, c3, want_logdet=False)
   rbar = torch.empty_like(r)

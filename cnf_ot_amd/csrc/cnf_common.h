@@ -197,6 +197,8 @@ static inline int wait_for_params(CnfModel* m, hipStream_t stream) {
 // into the stream's reserved workspace and returns them; CNF_ERR_UNSUPPORTED if the configuration has no table path
 // or the stream's reservation (cnf_model_reserve) is smaller than n.  Used by the table form of cnf_pass_vjp.
 int cnf_internal_build_tables(CnfModel* m, hipStream_t stream, const float* c, int64_t n, float** tables);
+int cnf_internal_flow_shared(CnfModel* m, hipStream_t stream, const float* in, const float* c, int64_t slice_len,
+                             int64_t n_slices, const float* tables, float* out);
 
 static inline cnf::ModelArgs model_args(const CnfModel* m) {
   cnf::ModelArgs a;

@@ -626,7 +626,8 @@ struct PwlArgs {
   // first_sample + s * slice_stride + j of the cnf_fill_normal stream of `seed`
   uint64_t seed;
   int64_t first_sample, slice_stride;
-};
+  int32_t in_shared;         // the slices share ONE set of input points in[slice_len, 2] (the same base draw pushed to
+};                           // several times: cnf_kinetic_potential_vjp)
 
 // Every reference call site hands the flow one time broadcast to cond[B,1] (applications.py:153,226,231):
 // per-sample in form, uniform in content.  For launches large enough for the table path this kernel checks it on
@@ -753,7 +754,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
   // Tile geometry is wave-uniform (scalar registers): the slice, the tile's first sample and how many of its
   // PWL_TS samples exist.  A lane's share is then a 32-bit offset from a scalar base address, and a full tile
   // -- every tile but the last of a slice of odd size -- takes the unmasked path.
-  struct Tile { int slice; int valid; int64_t g0; int64_t st0; };
+  struct Tile { int slice; int valid; int64_t g0; int64_t st0; int64_t gin; };
   auto tile_of = [&](int tile) {
     Tile t;
     t.slice = tile / a.tiles_per_slice;
@@ -763,6 +764,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
     const int64_t left = len - jt;
     t.valid = left >= PWL_TS ? PWL_TS : (left > 0 ? (int)left : 0);
     t.g0 = s0 + jt;
+    t.gin = a.in_shared ? jt : t.g0;
     t.st0 = a.first_sample + (int64_t)t.slice * a.slice_stride + jt;      // (seeded calls: the tile's first stream sample)
     return t;
   };
@@ -785,7 +787,7 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
       }
       return x;
     }
-    const float* p = a.in + 2 * t.g0;
+    const float* p = a.in + 2 * t.gin;
     if (t.valid == PWL_TS) x = *reinterpret_cast<const f4*>(p + 2u * lane2);
     else if ((int)lane2 + 1 < t.valid) x = *reinterpret_cast<const f4*>(p + 2u * lane2);
     else if ((int)lane2 < t.valid) { x[0] = p[2u * lane2]; x[1] = p[2u * lane2 + 1]; }
@@ -1675,7 +1677,9 @@ struct NoiseSrc { uint64_t seed; int64_t first_sample, slice_stride; };
 static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float* c, int64_t c_block,
                         float* out, float* aux, int aux_mode, int64_t B, hipStream_t stream,
                         bool detect = false, const uint32_t** gate = nullptr, uint32_t* gate_epoch = nullptr,
-                        const NoiseSrc* noise = nullptr) {
+                        const NoiseSrc* noise = nullptr, const float* built = nullptr, bool in_shared = false) {
+  // built: the slices' tables are in the stream's workspace already (cnf_internal_build_tables: one chunk);
+  // in_shared: `in` holds ONE slice of points that every slice reads
   if (!pwl_config_ok(m)) return CNF_ERR_UNSUPPORTED;
   const int L = m->cfg.num_layers;
   const bool precise = to_base && m->precise;
@@ -1731,7 +1735,7 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
     int64_t sets = 0;
     pwl_workspace(m, stream, &tables, &sets);
     if (sets < chunk) chunk = sets;
-    if (chunk < 1) return CNF_ERR_UNSUPPORTED;
+    if (chunk < 1 || (built && (chunk < n_slices || built != tables))) return CNF_ERR_UNSUPPORTED;
     if (m->use_pwl == 1 && chunk < n_slices && chunk * tps < (int64_t)m->num_cus) return CNF_ERR_UNSUPPORTED;
   }
   uint32_t* flag = nullptr;
@@ -1750,12 +1754,14 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
     const int64_t ns = n_slices - s0 < chunk ? n_slices - s0 : chunk;
     const int64_t first = s0 * slice_len;
     ProfScope ps(m, stream, true, (B - first) < ns * slice_len ? (B - first) : ns * slice_len, CNF_PATH_TABLES);
-    hipLaunchKernelGGL(cnf::pwl_build_kernel, dim3((unsigned)(ns * L)), dim3(512), 0, stream,
-                       (const float*)(m->prep + cnf::hdr_floats(5)), m->per_layer, c + s0, 0.0f, L, sp_offset, tables);
+    if (!built)
+      hipLaunchKernelGGL(cnf::pwl_build_kernel, dim3((unsigned)(ns * L)), dim3(512), 0, stream,
+                         (const float*)(m->prep + cnf::hdr_floats(5)), m->per_layer, c + s0, 0.0f, L, sp_offset, tables);
     ps.built();
     cnf::PwlArgs a;
     a.m = model_args(m);
-    a.in = in ? in + first * 2 : nullptr; a.out = out ? out + first * 2 : nullptr; a.aux = aux ? aux + first : nullptr;
+    a.in_shared = in_shared ? 1 : 0;
+    a.in = in ? in + (in_shared ? 0 : first * 2) : nullptr; a.out = out ? out + first * 2 : nullptr; a.aux = aux ? aux + first : nullptr;
     a.seed = noise ? noise->seed : 0; a.slice_stride = noise ? noise->slice_stride : 0;
     a.first_sample = noise ? noise->first_sample + s0 * noise->slice_stride : 0;
     a.tables = tables;
@@ -1770,6 +1776,14 @@ static int run_flow_pwl(CnfModel* m, bool to_base, const float* in, const float*
     ps.done();
   }
   return hipGetLastError() == hipSuccess ? CNF_OK : CNF_ERR_HIP;
+}
+
+// base -> data over n_slices slices of slice_len points each, all reading the ONE slice of points `in`, on tables
+// already built in the stream's workspace (cnf_kinetic_potential_vjp)
+int cnf_internal_flow_shared(CnfModel* m, hipStream_t stream, const float* in, const float* c, int64_t slice_len,
+                             int64_t n_slices, const float* tables, float* out) {
+  return run_flow_pwl(m, false, in, c, slice_len, out, nullptr, 0, n_slices * slice_len, stream, false, nullptr, nullptr,
+                      nullptr, tables, true);
 }
 
 int cnf_internal_build_tables(CnfModel* m, hipStream_t stream, const float* c, int64_t n, float** tables) {

@@ -801,6 +801,7 @@ struct VjpPwlArgs {
   float seed_coef;
   double* sums;
   uint32_t amax_bits;
+  int32_t pts_shared;    // the slices share ONE set of points pts[slice_len, 2] (cnf_kinetic_potential_vjp)
 };
 
 constexpr int VJP_PWL_THREADS = 512;      // two samples per lane: tiles of 1 024 samples
@@ -952,12 +953,13 @@ __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlAr
     t.x = f4{0.f, 0.f, 0.f, 0.f}; t.yb = t.x; t.ldb = v2f{0.f, 0.f};
     int slice; int64_t g; bool v0, v1;
     tile_geom(tile, slice, g, v0, v1);
+    const int64_t gp = a.pts_shared ? g - (int64_t)slice * a.slice_len : g;
     if (v1) {
-      t.x = *reinterpret_cast<const f4*>(a.pts + 2 * g);
+      t.x = *reinterpret_cast<const f4*>(a.pts + 2 * gp);
       if (a.ybar) t.yb = *reinterpret_cast<const f4*>(a.ybar + 2 * g);
       if (a.ldbar) t.ldb = *reinterpret_cast<const v2f*>(a.ldbar + g);
     } else if (v0) {
-      t.x[0] = a.pts[2 * g]; t.x[1] = a.pts[2 * g + 1];
+      t.x[0] = a.pts[2 * gp]; t.x[1] = a.pts[2 * gp + 1];
       if (a.ybar) { t.yb[0] = a.ybar[2 * g]; t.yb[1] = a.ybar[2 * g + 1]; }
       if (a.ldbar) t.ldb.x = a.ldbar[g];
     }
@@ -1416,7 +1418,8 @@ struct TermResidArgs {
   int64_t n, count;
   int32_t kind, D, subtype;
   float p0, loss_coef;
-};
+  uint32_t* amax;      // non-null (DFIX = 2, rbar written): [0] max |rbar| as bits, [1] non-finite flag -- what adjoint_max_kernel
+};                     // would find in rbar afterwards (cnf_kinetic_potential_vjp)
 
 // DFIX = 2: the points are float2 -- one 8-byte load / store per point instead of a strided loop.
 // The kernel is a stream of independent 8-byte accesses: 1 024-thread workgroups, RESID_PER points per thread a
@@ -1431,6 +1434,13 @@ __global__ __launch_bounds__(1024) void term_residual_kernel(const TermResidArgs
   const int D = DFIX ? DFIX : a.D;
   __shared__ double wsum[16];
   __shared__ long long wslice[16];
+  uint32_t amx = 0, abad = 0;
+  auto seen = [&](v2f gbar) {
+    const uint32_t bx = __float_as_uint(gbar.x) & 0x7fffffffu, by = __float_as_uint(gbar.y) & 0x7fffffffu;
+    const uint32_t b = bx > by ? bx : by;
+    abad |= b >= 0x7f800000u ? 1u : 0u;
+    amx = (b > amx && b < 0x7f800000u) ? b : amx;
+  };
   auto term = [&](int64_t i) -> float {      // the term's value at point i; writes the adjoints
     float v = 0.0f;
     if (DFIX == 2) {
@@ -1441,7 +1451,7 @@ __global__ __launch_bounds__(1024) void term_residual_kernel(const TermResidArgs
         const v2f dr = r2p[a.n + i] - r2p[i];
         const v2f w = dr * inv_dt;
         v = fmaf(w.x, w.x, w.y * w.y);
-        if (a.rbar) { rb2[i] = dr * -g; rb2[a.n + i] = dr * g; }
+        if (a.rbar) { rb2[i] = dr * -g; rb2[a.n + i] = dr * g; if (a.amax) seen(dr * g); }
       } else if (a.kind == CNF_TERM_POTENTIAL) {
         const v2f x = r2p[i];
         const float s2 = fmaf(x.x, x.x, x.y * x.y);
@@ -1451,7 +1461,7 @@ __global__ __launch_bounds__(1024) void term_residual_kernel(const TermResidArgs
         if (a.subtype == CNF_POT_DOUBLE_WELL) { v = 0.25f * sm * sp; gr = (xm * sp + xp * sm) * 0.5f; }      // applications.py:184-188
         else if (a.subtype == CNF_POT_OBSTACLE) { v = 50.0f * expf(-0.5f * s2); gr = x * -v; }                // :190-191
         else { v = 0.5f * s2; gr = x; }                                                                        // :181-182
-        if (a.rbar) rb2[i] = gr * a.loss_coef;
+        if (a.rbar) { rb2[i] = gr * a.loss_coef; if (a.amax) seen(gr * a.loss_coef); }
       } else {      // CNF_TERM_NEG_LOGPROB
         const v2f x = r2p[i];
         if (a.rbar) rb2[i] = x * a.loss_coef;
@@ -1526,10 +1536,24 @@ __global__ __launch_bounds__(1024) void term_residual_kernel(const TermResidArgs
       unsafeAtomicAdd(a.sums + slice, (double)v);      // a wave across a slice border: per lane
     }
   }
+  __shared__ uint32_t wmax[16];
+  if (DFIX == 2 && a.amax) {      // adjoint_max_kernel's result, without its pass over rbar
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(amx, off, 64); amx = o > amx ? o : amx; }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amx;
+    if (__builtin_amdgcn_ballot_w64(abad != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(a.amax + 1, 1u);
+  }
   const float part = wave_sum(acc);
   const int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { wsum[wv] = (double)part; wslice[wv] = cur; }
   __syncthreads();
+  if (DFIX == 2 && a.amax && threadIdx.x == 64) {
+    // one atomic per workgroup, and none where the maximum on record is already as large (a wave's atomic each put
+    // 130 000 of them on one address: +0.25 ms for config 5's kinetic + obstacle term)
+    uint32_t mm = 0;
+    for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) mm = wmax[w2] > mm ? wmax[w2] : mm;
+    if (mm > __hip_atomic_load(a.amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.amax, mm);
+  }
   if (threadIdx.x == 0) {
     const int nw = blockDim.x >> 6;
     double run = 0.0;
@@ -1747,9 +1771,12 @@ extern "C" int cnf_weighted_sum(const double* v, const double* w, int64_t n, dou
 // least min(n_slices, PWL_STAT_SLICES) slices.  CNF_ERR_UNSUPPORTED: the caller runs the MLP backward.
 // seed_sums != null: the density-fit form (cnf_neg_logprob_vjp) -- no adjoints come in, the kernel seeds itself with
 // seed_coef and writes the slices' sums of -log_prob.
+// built != null (cnf_kinetic_potential_vjp): the slices' tables are built (one chunk), the adjoint maximum is in place
+// (cnf_term_residual's kernel left it), and `pts` is ONE slice of points that every slice reads.
 static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float* c, int64_t c_block,
                         const float* ybar, const float* ldbar, float* xbar, float* grad, const float* params,
-                        int64_t B, hipStream_t stream, float seed_coef = 0.0f, double* seed_sums = nullptr) {
+                        int64_t B, hipStream_t stream, float seed_coef = 0.0f, double* seed_sums = nullptr,
+                        const float* built = nullptr) {
   const CnfConfig& g = m->cfg;
   if (!m->use_pwl || !m->fast_math || !m->pwl_stats || g.dim != 2 || g.hidden_size != PWL_H || g.num_bins != GK ||
       g.mlp_num_layers != 2 || g.num_layers > 4 || g.periodized)
@@ -1790,16 +1817,17 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     if (hipMemsetAsync(seed_sums, 0, sizeof(double) * (size_t)n_slices, stream) != hipSuccess) return CNF_ERR_HIP;
   }
   const int64_t tps = (slice_len + tile - 1) / tile;
+  if (built && n_slices > PWL_STAT_SLICES) return CNF_ERR_UNSUPPORTED;
   for (int64_t s0 = 0; s0 < n_slices; s0 += PWL_STAT_SLICES) {
     const int64_t ns = n_slices - s0 < PWL_STAT_SLICES ? n_slices - s0 : PWL_STAT_SLICES;
-    float* tables = nullptr;
-    const int r = cnf_internal_build_tables(m, stream, c + s0, ns, &tables);
+    float* tables = const_cast<float*>(built);
+    const int r = built ? CNF_OK : cnf_internal_build_tables(m, stream, c + s0, ns, &tables);
     if (r != CNF_OK) return s0 == 0 ? r : CNF_ERR_HIP;          // (a later chunk cannot fail on its own)
     m->last_path = CNF_PATH_TABLES;
     const int64_t first = s0 * slice_len;
     VjpPwlArgs a;
     a.m = model_args(m);
-    a.pts = pts + 2 * first; a.ybar = ybar ? ybar + 2 * first : nullptr; a.ldbar = ldbar ? ldbar + first : nullptr;
+    a.pts = pts + (built ? 0 : 2 * first); a.pts_shared = built ? 1 : 0; a.ybar = ybar ? ybar + 2 * first : nullptr; a.ldbar = ldbar ? ldbar + first : nullptr;
     a.xbar = xbar ? xbar + 2 * first : nullptr;
     uint32_t* amax = reinterpret_cast<uint32_t*>(m->pwl_stats);
     stat_t* stats = reinterpret_cast<stat_t*>(reinterpret_cast<char*>(m->pwl_stats) + 64);
@@ -1809,7 +1837,7 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
     a.slice_len = slice_len; a.n_slices = (int32_t)ns; a.tiles_per_slice = (int32_t)tps; a.acc_r = acc_r;
     a.seed_coef = seed_coef; a.sums = seeded ? seed_sums + s0 : nullptr; a.amax_bits = amax_bits;
     // (amax is zero on entry: cleared at allocation and by the grad_finish_kernel launch of the previous chunk or call)
-    if (!seeded)
+    if (!seeded && !built)
       hipLaunchKernelGGL(adjoint_max_kernel, dim3((unsigned)(m->num_cus * 4)), dim3(256), 0, stream, a.ybar, a.ybar ? 2 * a.B : 0, a.ldbar,
                        a.ldbar ? a.B : 0, amax);
     const int64_t tiles = ns * tps;
@@ -1895,6 +1923,52 @@ extern "C" int cnf_input_vjp(CnfModel* m, int to_base, const float* pts, const f
                              const float* ybar, const float* ldbar, float* xbar, int64_t B, void* stream) {
   if (!xbar) return CNF_ERR_INVALID;
   return pass_vjp_impl(m, to_base, pts, c, c_block, ybar, ldbar, xbar, nullptr, nullptr, B, stream);
+}
+
+extern "C" int cnf_kinetic_potential_vjp(CnfModel* m, const float* z, int64_t count, const float* c, int32_t S, float dt,
+                                         float c_kin, int32_t subtype, float pot_a, float c_pot, double* kin,
+                                         double* pot, float* grad, const float* params, float* work, void* stream_) {
+  if (!m || !z || !c || !kin || !grad || !params || !work || count < 1 || S < 1 || !(dt > 0.f)) return CNF_ERR_INVALID;
+  if ((subtype >= 0) != (pot != nullptr)) return CNF_ERR_INVALID;
+  if (!m->params_set || !m->grad_slabs) return CNF_ERR_INVALID;
+  {      // (pass_vjp_pwl's conditions, asked before anything is launched)
+    const CnfConfig& g = m->cfg;
+    if (!cnf_grad_supported(&g) || !m->use_pwl || !m->fast_math || !m->pwl_stats || g.dim != 2 || g.hidden_size != PWL_H ||
+        g.num_bins != GK || g.mlp_num_layers != 2 || g.num_layers > 4 || g.periodized)
+      return CNF_ERR_UNSUPPORTED;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t sets = pot ? 3 : 2, ns = sets * S, B = ns * count, n = (int64_t)S * count;
+  if (ns > PWL_STAT_SLICES || (count & 1) || (reinterpret_cast<uintptr_t>(work) & 15)) return CNF_ERR_UNSUPPORTED;
+  if (m->use_pwl == 1 && (count < 8192 || B < 524288)) return CNF_ERR_UNSUPPORTED;      // (pass_vjp_pwl's thresholds)
+  if (wait_for_params(m, stream) != CNF_OK) return CNF_ERR_HIP;
+  float* r = work;
+  float* rbar = work + 2 * B;
+  float* tables = nullptr;
+  int rc = cnf_internal_build_tables(m, stream, c, ns, &tables);
+  if (rc != CNF_OK) return rc;
+  rc = cnf_internal_flow_shared(m, stream, z, c, count, ns, tables, r);
+  if (rc != CNF_OK) return rc;                                   // (UNSUPPORTED: nothing but the tables was touched)
+  uint32_t* amax = reinterpret_cast<uint32_t*>(m->pwl_stats);    // zero on entry (pass_vjp_pwl)
+  if (hipMemsetAsync(kin, 0, sizeof(double) * (size_t)S, stream) != hipSuccess) return CNF_ERR_HIP;
+  if (pot && hipMemsetAsync(pot, 0, sizeof(double) * (size_t)S, stream) != hipSuccess) return CNF_ERR_HIP;
+  TermResidArgs a;
+  a.aux = nullptr; a.auxbar = nullptr; a.count = count; a.D = 2; a.amax = amax; a.n = n;
+  const int64_t blocks = (n + 1024 * RESID_PER - 1) / (1024 * RESID_PER);
+  a.r = r; a.rbar = rbar; a.sums = kin; a.kind = CNF_TERM_KINETIC; a.subtype = 0; a.p0 = dt; a.loss_coef = c_kin;
+  hipLaunchKernelGGL(term_residual_kernel<2>, dim3((unsigned)blocks), dim3(1024), 0, stream, a);
+  if (pot) {
+    a.r = r + 4 * n; a.rbar = rbar + 4 * n; a.sums = pot; a.kind = CNF_TERM_POTENTIAL; a.subtype = subtype; a.p0 = pot_a;
+    a.loss_coef = c_pot;
+    hipLaunchKernelGGL(term_residual_kernel<2>, dim3((unsigned)blocks), dim3(1024), 0, stream, a);
+  }
+  if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
+  rc = pass_vjp_pwl(m, 0, z, c, count, rbar, nullptr, nullptr, grad, params, B, stream, 0.0f, nullptr, tables);
+  if (rc != CNF_OK) {      // the adjoint maximum was left behind for a backward that did not run
+    (void)hipMemsetAsync(amax, 0, 8, stream);
+    return rc == CNF_ERR_UNSUPPORTED ? CNF_ERR_HIP : rc;
+  }
+  return CNF_OK;
 }
 
 extern "C" int cnf_neg_logprob_vjp(CnfModel* m, const float* pts, const float* c, int64_t c_block, float loss_coef,
@@ -2021,7 +2095,7 @@ extern "C" int cnf_term_residual(int32_t kind, const float* r, const float* aux,
   if (n == 0) return CNF_OK;
   TermResidArgs a;
   a.r = r; a.aux = aux; a.rbar = rbar; a.auxbar = auxbar; a.sums = sums; a.n = n; a.count = count;
-  a.kind = kind; a.D = D; a.subtype = subtype; a.p0 = p0; a.loss_coef = loss_coef;
+  a.kind = kind; a.D = D; a.subtype = subtype; a.p0 = p0; a.loss_coef = loss_coef; a.amax = nullptr;
   const int64_t blocks = (n + 1024 * cnf::RESID_PER - 1) / (1024 * cnf::RESID_PER);
   const bool vec2 = D == 2 && (reinterpret_cast<uintptr_t>(r) & 7) == 0 && (reinterpret_cast<uintptr_t>(rbar) & 7) == 0;
   if (vec2) hipLaunchKernelGGL(term_residual_kernel<2>, dim3((unsigned)blocks), dim3(1024), 0, stream, a);

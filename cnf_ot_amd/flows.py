@@ -569,6 +569,47 @@ class FlowEngine:
     _capi.check(rc, "cnf_neg_logprob_vjp")
     return sums
 
+  def kinetic_potential_vjp(self, z, conds, S: int, dt: float, c_kin: float, grad, subtype: int = -1, a: float = 0.0,
+                            c_pot: float = 0.0, kin=None, pot=None):
+    """cnf_kinetic_potential_vjp: per-time sums of the kinetic (and, subtype >= 0, the potential) term for the ONE
+    draw z [count, 2] pushed to the 2 S (3 S) conditions `conds`, and their gradient into `grad`.  Returns (kin, pot)
+    or None where the call does not apply (the caller composes the term from its parts)."""
+    z = self._points(z, "kinetic_potential_vjp")
+    count = z.shape[0]
+    sets = 3 if subtype >= 0 else 2
+    c = conds if (torch.is_tensor(conds) and conds.device == self.device and conds.dtype == torch.float32
+                  and conds.is_contiguous()) else torch.as_tensor(conds, dtype=torch.float32, device=self.device).contiguous()
+    if c.numel() != sets * S:
+      raise ValueError(f"kinetic_potential_vjp: {sets * S} conditions expected, got {c.numel()}")
+    if not self._pwl_mode or count == 0 or self.cfg.dim != 2:
+      return None
+    if self._flat is None:
+      raise RuntimeError("load(params) before asking for gradients")
+    if not getattr(self, "_grad_enabled", False):
+      with _OnDevice(self.device):
+        _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
+      self._grad_enabled = True
+    self._check_out(grad, (self.cfg.param_count(),), "grad")
+    if sets * S > 128:
+      return None
+    self.reserve(sets * S)
+    kin = torch.empty(S, dtype=torch.float64, device=self.device) if kin is None else kin
+    if subtype >= 0 and pot is None:
+      pot = torch.empty(S, dtype=torch.float64, device=self.device)
+    need = 4 * sets * S * count
+    work = getattr(self, "_kp_work", None)
+    if work is None or work.numel() < need:
+      work = self._kp_work = torch.empty(need, dtype=torch.float32, device=self.device)
+    with _OnDevice(self.device):
+      rc = self.lib.cnf_kinetic_potential_vjp(self._h, z.data_ptr(), count, c.data_ptr(), int(S), float(dt), float(c_kin),
+                                              int(subtype), float(a), float(c_pot), kin.data_ptr(),
+                                              pot.data_ptr() if subtype >= 0 else None, grad.data_ptr(),
+                                              self._flat.data_ptr(), work.data_ptr(), _stream_ptr(self.device))
+    if rc == _capi.CNF_ERR_UNSUPPORTED:
+      return None
+    _capi.check(rc, "cnf_kinetic_potential_vjp")
+    return kin, pot
+
   def logprob_fd(self, pts, cond, dx: float) -> torch.Tensor:
     """cnf_logprob_fd: the central-difference score [B, D] of log_prob at pts."""
     pts = self._points(pts, "logprob_fd")

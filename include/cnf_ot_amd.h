@@ -358,6 +358,23 @@ int cnf_neg_logprob_vjp(CnfModel *m, const float *pts, const float *c,
                         float *grad, const float *params, int64_t B,
                         void *stream);
 
+/* Value and gradient of the kinetic (+ potential) term of ot_loss_fn in one call (kinetic_loss_fn / potential_loss_fn,
+ * applications.py:176-242, as ot_loss_fn combines them, :388-402, under jax.value_and_grad, solvers.py:94): the ONE
+ * base draw z [count, 2] pushed to the S times t_s - dt/2, t_s + dt/2 and -- with subtype >= 0 (CnfPotential) -- t_s:
+ *   kin[s] = sum_i |(r2_i - r1_i) / dt|^2,  pot[s] = sum_i V(r3_i),
+ *   grad[p] += c_kin d(sum_s kin[s]) / dp + c_pot d(sum_s pot[s]) / dp.
+ * c: the 2 S (3 S) conditions [t - dt/2 | t + dt/2 | t] as the caller rounds them.  One table build, one forward
+ * launch in which all slices read the same z (no repeated copy of it), the term epilogues, which also leave the largest
+ * adjoint for the backward (no scan), and one backward launch -- what cnf_sample + cnf_term_residual + cnf_pass_vjp do
+ * in six launches over 2 (3) S repeated copies of z.  work: 4 x 2 (3) S x count floats, 16-byte aligned (the pushed
+ * points and their adjoints).  pot == NULL iff subtype < 0.  CNF_ERR_UNSUPPORTED (nothing written) where the table
+ * backward does not apply or 2 (3) S > 128: compose the term from those calls. */
+int cnf_kinetic_potential_vjp(CnfModel *m, const float *z, int64_t count,
+                              const float *c, int32_t S, float dt, float c_kin,
+                              int32_t subtype, float pot_a, float c_pot,
+                              double *kin, double *pot, float *grad,
+                              const float *params, float *work, void *stream);
+
 /* The score of the flow's density by central differences, the way the reference
  * forms it (kinetic_with_score_loss_fn / flow_matching_loss_fn,
  * applications.py:264-273; utils.py:366-381):

@@ -579,9 +579,10 @@ def test_value_and_grad_through_the_table_backward(dev, subtype, monkeypatch):
   used = []
   monkeypatch.setattr(app, "TABLE_BACKWARD_MIN_SLICE", 256)
   monkeypatch.setattr(app, "TABLE_BACKWARD_MIN_POINTS", 256)
-  orig, orig_nlp = be.pass_vjp, be.neg_logprob_vjp
+  orig, orig_nlp, orig_kp = be.pass_vjp, be.neg_logprob_vjp, be.kinetic_potential_vjp
   monkeypatch.setattr(be, "pass_vjp", lambda *a, **k: (used.append(1), orig(*a, **k))[1])
   monkeypatch.setattr(be, "neg_logprob_vjp", lambda *a, **k: (used.append(1), orig_nlp(*a, **k))[1])
+  monkeypatch.setattr(be, "kinetic_potential_vjp", lambda *a, **k: (used.append(1), orig_kp(*a, **k))[1])
   be.set_pwl(2)
   loss2, g2 = vg(params, 11, 50.0, B)
   torch.cuda.synchronize()
@@ -591,6 +592,47 @@ def test_value_and_grad_through_the_table_backward(dev, subtype, monkeypatch):
   eg = (g2.flat - g0.flat).abs().max().item() / g0.flat.abs().max().item()
   print(f"\n[ot {subtype}: table backward vs fused kernel] loss rel {el:.2e} grad rel {eg:.2e}")
   assert el <= 2e-5 and eg <= 2e-4
+
+
+@pytest.mark.parametrize("subtype", [None, "obstacle", "double_well"])
+@pytest.mark.parametrize("S,count", [(1, 70002), (5, 9000), (32, 8194)])
+def test_kinetic_potential_vjp_equals_the_composed_terms(dev, subtype, S, count):
+  """cnf_kinetic_potential_vjp (kinetic_loss_fn + potential_loss_fn as ot_loss_fn combines them, applications.py:176-242,
+  388-402, under jax.value_and_grad) against the same terms composed from cnf_sample on repeated copies of z +
+  cnf_term_residual + cnf_pass_vjp: the same tables, kernels and adjoints, so sums to 1e-12 and the gradient BIT FOR BIT."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params, _capi
+  cfg = FlowConfig(dim=2)
+  params = Params.random(cfg, 0.2, seed=4, device=dev)
+  eng = FlowEngine(cfg, dev).load(params)
+  eng.set_pwl(2)
+  g = torch.Generator(device="cpu").manual_seed(S + count)
+  z = torch.randn(count, 2, generator=g).to(dev)
+  t = torch.linspace(0.1, 0.9, S, device=dev)
+  dt, c_kin, c_pot, a = 0.01, 0.37 / count, 0.11 / count, 1.5
+  half = np.float32(0.5 * dt)
+  sets = [t - half, t + half] + ([t] if subtype else [])
+  c = torch.cat(sets).contiguous()
+  n = S * count
+  g1 = torch.zeros(cfg.param_count(), device=dev)
+  out = eng.kinetic_potential_vjp(z, c, S, dt, c_kin, g1, subtype=_capi.POTENTIALS[subtype] if subtype else -1, a=a, c_pot=c_pot)
+  assert out is not None and eng.last_path() == "tables"
+  kin1, pot1 = out
+  zr = z.repeat(len(sets) * S, 1)
+  r, _ = eng.forward_logdet(zr, c, want_logdet=False)
+  rbar = torch.empty_like(r)
+  kin0, _, _ = eng.term_residual(_capi.TERM_KINETIC, r[:2 * n], None, count, p0=dt, loss_coef=c_kin, rbar_out=rbar[:2 * n])
+  if subtype:
+    pot0, _, _ = eng.term_residual(_capi.TERM_POTENTIAL, r[2 * n:], None, count, subtype=_capi.POTENTIALS[subtype], p0=a,
+                                   loss_coef=c_pot, rbar_out=rbar[2 * n:])
+  g0 = torch.zeros_like(g1)
+  eng.pass_vjp(zr, c, rbar, None, False, grad=g0, want_xbar=False)
+  torch.cuda.synchronize()
+  torch.testing.assert_close(kin1, kin0, rtol=1e-12, atol=0)
+  if subtype:
+    torch.testing.assert_close(pot1, pot0, rtol=1e-12, atol=0)
+  else:
+    assert pot1 is None
+  assert torch.equal(g1, g0)
 
 
 @pytest.mark.parametrize("L", [2, 3])
