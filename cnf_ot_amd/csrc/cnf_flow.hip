@@ -487,6 +487,12 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
     T base = splat<T>(0.0f);
     if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = base_logprob<T>(U + SPL * threadIdx.x, DD, TS);
     BaseAcc<T> bacc;
+    // data -> base: the splines' clamps and bin searches turn a NaN coordinate into a finite point (log_prob(NaN) came
+    // out as -58.9); the reference's arithmetic propagates it.  v - v is 0 for a finite v and NaN otherwise.
+    [[maybe_unused]] T poison = splat<T>(0.0f);
+    if constexpr (TO_BASE) {
+      for (int d = 0; d < DD; ++d) { const T v = lds_get<T>(U + SPL * threadIdx.x, d, TS); poison += v - v; }
+    }
     const T acc = flow_pass<H, K, TO_BASE, FAST, T, MFMA, PRECISE, PERIODIC, DFIX>(a.m, tab, U, O, c, e2tab, tabd, LO, &bacc);
     if (a.aux) {
       T r = acc;
@@ -495,10 +501,14 @@ __global__ __launch_bounds__(TILE, 2) void flow_kernel(const FlowArgsT<typename 
         if constexpr (PRECISE) r = bacc.log_prob(acc, DD);
         else r = TO_BASE ? base_logprob<T>(U + SPL * threadIdx.x, DD, TS) + acc : base - acc;
       }
+      if constexpr (TO_BASE) r += poison;
       if (TO_BASE && !PRECISE && a.fd2) store_fd(a, i, r);
       else store_aux(a.aux, i, a.B, r);
     }
     if (a.out) {
+      if constexpr (TO_BASE) {
+        for (int d = 0; d < DD; ++d) lds_put(U + SPL * threadIdx.x, d, TS, lds_get<T>(U + SPL * threadIdx.x, d, TS) + poison);
+      }
       __syncthreads();
       tile_store<R>(a.out, U, DD, dmagic, TS, tile_start, a.B);
     }
@@ -812,6 +822,8 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
     if (tile + 1 < t1) xn = tile_points(tile_of(tile + 1));
     __builtin_amdgcn_sched_barrier(0);
     v2f u0 = {x[0], x[2]}, u1 = {x[1], x[3]};
+    [[maybe_unused]] v2f poison = splat<v2f>(0.0f);      // (flow_kernel: a NaN coordinate must come out as NaN)
+    if constexpr (TO_BASE) poison = (u0 - u0) + (u1 - u1);
 
     v2f base = splat<v2f>(0.0f);
     if (!TO_BASE && a.aux_mode == AUX_LOGPROB && a.aux) base = (u0 * u0 + u1 * u1) * -0.5f - (float)(2 * HALF_LOG_2PI);
@@ -823,12 +835,14 @@ __global__ __launch_bounds__(PWL_MAX_THREADS) void flow_pwl_kernel(const PwlArgs
       if constexpr (PRECISE) { if (a.aux_mode == AUX_LOGPROB) r = bacc.log_prob(acc, 2); }
       else if (a.aux_mode == AUX_LOGPROB)
         r = TO_BASE ? (u0 * u0 + u1 * u1) * -0.5f - (float)(2 * HALF_LOG_2PI) + acc : base - acc;
+      if constexpr (TO_BASE) r += poison;
       float* q = a.aux + tl.g0;
       if (full || v1) *reinterpret_cast<v2f*>(q + lane2) = r;
       else if (v0) q[lane2] = r.x;
     }
     if (a.out) {
       float* q = a.out + 2 * tl.g0;
+      if constexpr (TO_BASE) { u0 += poison; u1 += poison; }
       if (full || v1) *reinterpret_cast<f4*>(q + 2u * lane2) = f4{u0.x, u1.x, u0.y, u1.y};
       else if (v0) { q[2u * lane2] = u0.x; q[2u * lane2 + 1] = u1.x; }
     }

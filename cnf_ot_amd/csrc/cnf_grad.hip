@@ -980,6 +980,9 @@ __global__ __launch_bounds__(VJP_PWL_THREADS) void vjp_pwl_kernel(const VjpPwlAr
     v2f ld_bar = nxt.ldb;
     if (tile + 1 < t1) nxt = tile_load(tile + 1);
     __builtin_amdgcn_sched_barrier(0);
+    // a non-finite POINT would pass unnoticed (the table search and the splines' clamps turn it into some finite
+    // point): it poisons the call's gradient like a non-finite adjoint does
+    if (!(fabsf((x[0] + x[1]) + (x[2] + x[3])) < INFINITY)) atomicOr(a.amax + 1, 1u);
     v2f u0 = {x[0], x[2]}, u1 = {x[1], x[3]};
     v2f ob0 = {yb[0], yb[2]}, ob1 = {yb[1], yb[3]};
     [[maybe_unused]] v2f lacc = splat<v2f>(0.0f);      // SEED: the pass's log|det J|

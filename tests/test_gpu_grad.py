@@ -594,6 +594,49 @@ def test_value_and_grad_through_the_table_backward(dev, subtype, monkeypatch):
   assert el <= 2e-5 and eg <= 2e-4
 
 
+def test_fused_term_calls_decline_flag_and_recover(dev):
+  """cnf_neg_logprob_vjp / cnf_kinetic_potential_vjp at their edges: below the table backward's thresholds (default
+  table mode) and past 128 slices they decline (None: the caller composes the term) and leave the gradient untouched;
+  a non-finite data point or draw turns the call's gradient into NaN (as the composed path does:
+  test_table_backward_does_not_hide_non_finite_adjoints) and the next call is clean; odd slice lengths decline."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  cfg = FlowConfig(dim=2)
+  params = Params.random(cfg, 0.2, seed=6, device=dev)
+  eng = FlowEngine(cfg, dev).load(params)
+  gen = torch.Generator(device="cpu").manual_seed(8)
+  n = 20000
+  pts = torch.randn(n, 2, generator=gen).to(dev)
+  z = torch.randn(n, 2, generator=gen).to(dev)
+  g = torch.zeros(cfg.param_count(), device=dev)
+  t1 = torch.tensor([0.3], device=dev)
+  c2 = torch.tensor([0.295, 0.305], device=dev)
+  # default table mode: 20 000 points are below the thresholds
+  assert eng.neg_logprob_vjp(pts, t1, 0.01, g) is None
+  assert eng.kinetic_potential_vjp(z, c2, 1, 0.01, 0.5, g) is None
+  assert g.abs().max().item() == 0.0
+  eng.set_pwl(2)
+  # more slices than one chunk of statistics (kinetic: 2 S > 128), an odd slice length with several slices
+  zs = z[:1024].contiguous()
+  assert eng.kinetic_potential_vjp(zs, torch.linspace(0.1, 0.9, 130, device=dev), 65, 0.01, 0.5, g) is None
+  assert eng.kinetic_potential_vjp(z[:9001].contiguous(), c2, 1, 0.01, 0.5, g) is None
+  assert g.abs().max().item() == 0.0
+  # a non-finite input: NaN gradient, then a clean call
+  for bad in (float("nan"), float("inf")):
+    p2 = pts.clone(); p2[777, 0] = bad
+    gb = torch.zeros_like(g)
+    assert eng.neg_logprob_vjp(p2, t1, 0.01, gb) is not None
+    assert not torch.isfinite(gb).all()
+    z2 = z.clone(); z2[4321, 1] = bad
+    gb = torch.zeros_like(g)
+    assert eng.kinetic_potential_vjp(z2, c2, 1, 0.01, 0.5, gb) is not None
+    assert not torch.isfinite(gb).all()
+    for call in (lambda gg: eng.neg_logprob_vjp(pts, t1, 0.01, gg), lambda gg: eng.kinetic_potential_vjp(z, c2, 1, 0.01, 0.5, gg)):
+      gc = torch.zeros_like(g)
+      assert call(gc) is not None
+      assert torch.isfinite(gc).all() and gc.abs().max().item() > 0
+  eng.set_pwl(1)
+
+
 @pytest.mark.parametrize("subtype", [None, "obstacle", "double_well"])
 @pytest.mark.parametrize("S,count", [(1, 70002), (5, 9000), (32, 8194)])
 def test_kinetic_potential_vjp_equals_the_composed_terms(dev, subtype, S, count):

@@ -703,6 +703,48 @@ def test_wild_params_no_worse_than_fp32_port(dev, golden_dir, pwl):
   assert np.quantile(e_gpu, 0.99) <= 2 * np.quantile(e_port, 0.99) + 1e-5
 
 
+@pytest.mark.parametrize("D", [2, 3])
+def test_non_finite_points_come_out_non_finite(dev, D):
+  """data -> base (log_prob / inverse, conditional.py:299-321): a NaN or infinite coordinate must not come back as a
+  finite number -- the splines' clamps and bin searches used to turn a NaN into the point -10 and log_prob(NaN) into
+  -58.9, where the reference's arithmetic (and the float64 oracle: NaN / -inf) propagates it.  Every kernel that serves
+  the direction (tables, MLP at 1 and 2 samples per lane, MFMA, the precise and the plain position path), and the
+  samples around the bad ones unchanged."""
+  from cnf_ot_amd import FlowConfig, FlowEngine, Params
+  from oracle import capi as ocapi
+  cfg = FlowConfig(dim=D)
+  params = Params.random(cfg, 0.2, seed=5, device=dev)
+  eng = FlowEngine(cfg, dev).load(params)
+  B = 1 << 18
+  g = torch.Generator(device="cpu").manual_seed(D)
+  x = torch.randn(B, D, generator=g).to(dev)
+  bad_rows = [5, 70001, B - 1]
+  ocfg = ocapi.OracleConfig(D=D)
+  pnp = params.flat.cpu().numpy().astype(np.float64)
+  for bad in (float("nan"), float("inf"), -float("inf")):
+    x2 = x.clone()
+    for k, r in enumerate(bad_rows):
+      x2[r, k % D] = bad
+    want = ocapi.log_prob(ocfg, pnp, x2[bad_rows].cpu().numpy().astype(np.float64), np.full((len(bad_rows), 1), 0.3))
+    assert not np.isfinite(want).any()
+    for mode in ((0, 2) if D == 2 else (0,)):
+      eng.set_pwl(mode)
+      for precise in (True, False):
+        eng.set_precise(precise)
+        for n in (B, 4096):      # (small launches: the MFMA kernel)
+          lp_clean = eng.log_prob(x[:n], 0.3)
+          lp = eng.log_prob(x2[:n], 0.3)
+          z, ild = eng.inverse_logdet(x2[:n], 0.3)
+          rows = [r for r in bad_rows if r < n]
+          for r in rows:
+            assert not torch.isfinite(lp[r]), (bad, mode, precise, n, r, lp[r].item(), eng.last_path())
+            assert not torch.isfinite(ild[r]) or not torch.isfinite(z[r]).all(), (bad, mode, precise, n, r)
+          keep = torch.ones(n, dtype=torch.bool, device=dev); keep[rows] = False
+          # (not bit for bit: a wave evaluates the general form of a spline when ANY of its lanes needs it)
+          torch.testing.assert_close(lp[keep], lp_clean[keep], rtol=0, atol=2e-5)
+  eng.set_precise(True); eng.set_pwl(1)
+
+
 def test_roundtrip_and_consistency_at_full_size(dev):
   """Size-independent properties at BASELINE sizes (no oracle needed):
   inverse(forward(x)) == x, logdets antisymmetric, log_prob(sample) equals the
