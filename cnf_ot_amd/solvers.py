@@ -123,6 +123,12 @@ class CapturedUpdate:
     self.vg = applications.value_and_grad(loss_fn)
     self.opt, self.B, self.replay = optimizer, batch_size, replay
     self.rng, self.graph, self.loss, self._key, self._calls = None, None, None, None, 0
+    # The warm-up steps run on the stream the graph is captured on: the engine's table workspaces are reserved PER
+    # STREAM and cannot grow during a capture (FlowEngine.reserve), so a step warmed up on the caller's stream and
+    # captured on torch's side stream found no tables there and recorded the MLP kernels -- correct, and for a
+    # large batch several times slower than the eager step (found by the ot_large case of
+    # test_captured_step_equals_the_eager_step_bit_for_bit).
+    self._stream = None
 
   def _body(self, params, _lambda, opt_state):
     dev = params.flat.device
@@ -141,13 +147,22 @@ class CapturedUpdate:
     self._key = key
     self.rng.set_key(rng)
     self._calls += 1
-    if not self.replay or self._calls <= self.WARMUP:
+    if not self.replay:
       self.loss = self._body(params, _lambda, opt_state)
+    elif self._calls <= self.WARMUP:
+      dev = params.flat.device
+      if self._stream is None:
+        self._stream = torch.cuda.Stream(device=dev)
+      cur = torch.cuda.current_stream(dev)
+      self._stream.wait_stream(cur)
+      with torch.cuda.stream(self._stream):
+        self.loss = self._body(params, _lambda, opt_state)
+      cur.wait_stream(self._stream)
     elif self.graph is None:
       torch.cuda.synchronize(params.flat.device)
       graph = torch.cuda.CUDAGraph()
       step0 = opt_state.step
-      with torch.cuda.graph(graph):
+      with torch.cuda.graph(graph, stream=self._stream):
         self.loss = self._body(params, _lambda, opt_state)
       opt_state.step = step0            # (the capture only recorded the step)
       self.graph = graph

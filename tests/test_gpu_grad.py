@@ -257,14 +257,17 @@ def test_adam_step_and_training_decreases_loss(dev):
   assert np.isfinite(last) and last < first
 
 
-@pytest.mark.parametrize("kind", ["ot", "rwpo"])
+@pytest.mark.parametrize("kind", ["ot", "rwpo", "ot_large"])
 def test_captured_step_equals_the_eager_step_bit_for_bit(dev, kind):
   """solvers.CapturedUpdate: `update` (solvers.py:90-97) captured into one HIP graph -- key, time batch, mixture
   components, base noise and Adam's step count all read from device memory -- against the very same body run
   eagerly: after 10 steps from the same start the parameters and both Adam moments are the same BITS, and every
   step's loss too."""
   from cnf_ot_amd import solvers
-  ov = {"general": {"type": kind, "t_batch_size": 2}, "train": {"batch_size": 2048, "lr": 1e-3}}
+  B = 2048
+  if kind == "ot_large":      # a batch whose terms run as the fused table-backward calls (cnf_neg_logprob_vjp, cnf_kinetic_potential_vjp)
+    kind, B = "ot", 1 << 21
+  ov = {"general": {"type": kind, "t_batch_size": 8 if B > 2048 else 2}, "train": {"batch_size": B, "lr": 1e-3}}
   config = solvers.load_config(overrides=ov)
   res = []
   for replay in (False, True):
@@ -272,7 +275,7 @@ def test_captured_step_equals_the_eager_step_bit_for_bit(dev, kind):
     params = model.init(7)
     params.flat.add_(0.05 * torch.randn(params.flat.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1)))
     opt = solvers.Adam(1e-3); st = opt.init(params)
-    upd = solvers.CapturedUpdate(solvers.bind_loss(config, model), opt, 2048, replay=replay)
+    upd = solvers.CapturedUpdate(solvers.bind_loss(config, model), opt, B, replay=replay)
     losses = []
     for step in range(10):
       loss, params, st = upd(params, 1000 + 17 * step, 5000.0, st)
