@@ -34,6 +34,7 @@ from .flows import DeviceRng, _OnDevice, _stream_ptr, seed_to_u64
 # 256-thread host (LAPACK thread start-up) -- it was 35 of the 41 ms of config 5's value_and_grad.
 GAUSSIAN_SOURCE_CHOL = np.linalg.cholesky(np.array([[5.0, 1.0], [1.0, 0.5]])).astype(np.float32)
 _CHOL_ROWS = {}        # device -> the factor's rows on that device
+_CENTERS_DEV = {}      # device -> MIXTURE_CENTERS on that device
 MIXTURE_R = 5.0
 # applications.py:34-67: centres of the 8-mode mixture source
 MIXTURE_CENTERS = MIXTURE_R * np.array(
@@ -79,8 +80,10 @@ def _cat_conds(parts):
 
 
 def draw_components(rng, n: int) -> np.ndarray:
-  """jax.random.choice(seed, a=8, shape=(n,)) (applications.py:36-38)."""
-  return host_rng(rng, 2).integers(0, 8, size=n)
+  """jax.random.choice(seed, a=8, shape=(n,)) (applications.py:36-38).  One byte per draw: the default int64 draw took
+  5 ms per million on the GPU box's host and its [n, 2] table of centres another 5 plus a 16 MB copy -- an eager
+  large-batch step with the mixture source was 15 ms of host work around 0.5 ms of kernels."""
+  return host_rng(rng, 2).integers(0, 8, size=n, dtype=np.uint8)
 
 
 class _Ctx:
@@ -288,8 +291,10 @@ def _source_samples(ctx, z, start, count, n_global, source):
                                                        _stream_ptr(z.device)), "cnf_mixture_source_dev")
       return out
     comp = draw_components(ctx.rng, n_global)[start:start + count]
-    centers = torch.from_numpy(MIXTURE_CENTERS[comp]).to(z.device)
-    return z + centers
+    cdev = _CENTERS_DEV.get(z.device)
+    if cdev is None:
+      cdev = _CENTERS_DEV[z.device] = torch.from_numpy(MIXTURE_CENTERS).to(z.device)
+    return z + cdev[torch.from_numpy(np.ascontiguousarray(comp)).to(z.device).long()]      # (the bytes cross, not the centres)
   if source == "gaussian":     # applications.py:28-32 (commented Gaussian source; BASELINE configs)
     if z.shape[1] != 2:
       raise ValueError("the Gaussian source N(-3, A) is 2-D (applications.py:28-32)")
