@@ -5,7 +5,7 @@ import torch
 from cnf_ot_amd import solvers
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 for sub in ("free", "obstacle"):
-  ov = {"general": {"type": "ot", "t_batch_size": 8, "subtype": sub}, "train": {"batch_size": 1 << 21, "lr": 1e-3}}
+  ov = {"general": {"type": "ot", "t_batch_size": 8}, "ot": {"subtype": sub}, "train": {"batch_size": 1 << 21, "lr": 1e-3}}
   config = solvers.load_config(overrides=ov)
   for capture in (False, True):
     torch.cuda.synchronize(); t0 = time.perf_counter()
