@@ -140,6 +140,10 @@ class CapturedUpdate:
 
   def __call__(self, params: Params, rng, _lambda, opt_state: AdamState):
     if self.rng is None:
+      from .distributed import current_shard
+      if self.replay and current_shard().world > 1:
+        # (the loss's all-reduce would be recorded into the graph: RCCL can, gloo cannot, and neither has been run here)
+        raise NotImplementedError("CapturedUpdate: single rank only -- use the eager update under torch.distributed")
       self.rng = DeviceRng(params.flat.device)
     key = (params.flat.data_ptr(), opt_state.mu.data_ptr(), opt_state.nu.data_ptr(), float(_lambda))
     if self._key is not None and key != self._key:

@@ -103,6 +103,13 @@ def _vg_worker(rank, world, port, q):
       loss = app.ot_loss_fn(model, 2, 1.0, 0.01, 2, "obstacle", params, 42, 5000.0, 256, source="gaussian", grad=g,
                             overlap=overlap)
       out[name] = (float(loss), g.numpy().copy())
+    # the captured step is single-rank: under a process group it says so instead of recording a collective
+    from cnf_ot_amd import solvers
+    try:
+      solvers.CapturedUpdate(lambda *a, **k: None, solvers.Adam(1e-3), 256)(params, 1, 1.0, None)
+      out["captured"] = "ran"
+    except NotImplementedError as e:
+      out["captured"] = str(e)
     q.put((rank, out))
   finally:
     dist.destroy_process_group()
@@ -136,6 +143,7 @@ def test_overlapped_allreduce_equals_the_blocking_one(oracle_lib):
     lo, go = results[rank]["overlapped"]
     assert abs(lo - lb) <= 1e-12 * abs(lb) and np.abs(go - gb).max() <= 1e-12 * scale
     assert abs(lb - l1) <= 1e-9 * abs(l1) and np.abs(gb - g1.numpy()).max() <= 1e-6 * scale      # (finite-difference gradients)
+    assert "single rank" in results[rank]["captured"]
 
 
 def test_host_composition_matches_reference_restatement(oracle_lib):
