@@ -311,10 +311,10 @@ def _source_samples(ctx, z, start, count, n_global, source):
 # The fused gradient kernel evaluates the conditioner MLP per sample and multiplies per-sample weight gradients on
 # the matrix cores (4 G flow passes/s); cnf_pass_vjp on the conditioner tables needs neither (per-piece sufficient
 # statistics: DESIGN.md 5.4, 9 G passes/s).  So when a rank's share of a term is large enough for the tables
-# (cnf_grad.hip: slices >= 8 192 points, >= 524 288 points per pass) the term is ONE forward launch on the tables,
+# (cnf_grad.hip: slices >= 8 192 points, >= 262 144 points per pass) the term is ONE forward launch on the tables,
 # a few elementwise kernels for its value and adjoints, and ONE table backward launch.
 TABLE_BACKWARD_MIN_SLICE = 8192
-TABLE_BACKWARD_MIN_POINTS = 524288
+TABLE_BACKWARD_MIN_POINTS = 262144
 
 
 def _use_table_backward(ctx, dim, count, n_slices, passes=1):

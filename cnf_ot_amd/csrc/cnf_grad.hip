@@ -1788,10 +1788,10 @@ static int pass_vjp_pwl(CnfModel* m, int to_base, const float* pts, const float*
   const int64_t slice_len = c_block < B ? c_block : B;
   const int64_t n_slices = (B + slice_len - 1) / slice_len;
   // worth it while a slice amortises its tables and their per-piece finishing (measured crossover: see DESIGN.md)
-  // (measured, scripts/exp_vjp_tables.py: 4.2 M points 0.46 vs 0.94 ms for the MLP backward, 131 072 points 0.085 vs
-  // 0.050 ms: ~0.06 ms of fixed cost -- table build, adjoint maximum, per-piece finishing -- against 0.12 us saved per
-  // 1 000 points)
-  if (m->use_pwl == 1 && (slice_len < 8192 || B < 524288)) return CNF_ERR_UNSUPPORTED;
+  // (measured, scripts/exp_vjp_crossover.py, round 3's kernel: 131 072 points 0.049 vs 0.044 ms for the MLP backward,
+  // 262 144 points 0.056 vs 0.066 -- 32 slices of 8 192: 0.062 vs 0.066 --, 524 288 points 0.072 vs 0.110; slices of
+  // 4 096 points lose until there are ~100 of them.  Round 2's kernel crossed over at twice that.)
+  if (m->use_pwl == 1 && (slice_len < 8192 || B < 262144)) return CNF_ERR_UNSUPPORTED;
   // (a lane's two samples are one 16-byte access of the points and adjoints, one 8-byte access of ldbar)
   if ((reinterpret_cast<uintptr_t>(pts) & 15) || (reinterpret_cast<uintptr_t>(ybar) & 15) ||
       (reinterpret_cast<uintptr_t>(xbar) & 15) || (reinterpret_cast<uintptr_t>(ldbar) & 7) || (n_slices > 1 && (slice_len & 1)))
@@ -1943,7 +1943,7 @@ extern "C" int cnf_kinetic_potential_vjp(CnfModel* m, const float* z, int64_t co
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t sets = pot ? 3 : 2, ns = sets * S, B = ns * count, n = (int64_t)S * count;
   if (ns > PWL_STAT_SLICES || (count & 1) || (reinterpret_cast<uintptr_t>(work) & 15)) return CNF_ERR_UNSUPPORTED;
-  if (m->use_pwl == 1 && (count < 8192 || B < 524288)) return CNF_ERR_UNSUPPORTED;      // (pass_vjp_pwl's thresholds)
+  if (m->use_pwl == 1 && (count < 8192 || B < 262144)) return CNF_ERR_UNSUPPORTED;      // (pass_vjp_pwl's thresholds)
   if (wait_for_params(m, stream) != CNF_OK) return CNF_ERR_HIP;
   float* r = work;
   float* rbar = work + 2 * B;

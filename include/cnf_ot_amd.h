@@ -336,7 +336,7 @@ int cnf_input_vjp(CnfModel *m, int to_base, const float *pts, const float *c,
  * torch.autograd: cnf_ot_amd/autograd.py) gets exact gradients -- what
  * jax.value_and_grad gives the reference for losses not in applications.py.
  * xbar may be NULL; grad is accumulated (needs cnf_grad_enable).
- * At dim 2, with a condition that is uniform over slices (c_block >= 8 192) and >= 524 288 points, and tables
+ * At dim 2, with a condition that is uniform over slices (c_block >= 8 192) and >= 262 144 points, and tables
  * reserved on the stream for min(n_slices, 128) slices (cnf_model_reserve), the pass runs on the conditioner tables:
  * per-piece sufficient statistics in 64-bit fixed point instead of per-sample weight gradients --
  * same result to ~1e-6, about twice as fast, bitwise reproducible.  Nothing is allocated here: the statistics
