@@ -324,12 +324,21 @@ def _use_table_backward(ctx, dim, count, n_slices, passes=1):
           and count * n_slices * passes >= TABLE_BACKWARD_MIN_POINTS)
 
 
+def _use_table_values(ctx, dim, count, n_slices, passes=1):
+  """The same composition for the loss WITHOUT its gradient (table forward + term epilogue: 70 G flow passes/s where the
+  fused loss kernel, three table sets in LDS, does 39 -- config 5's share 0.54 -> 0.3 ms)."""
+  be = ctx.be
+  return (ctx.grad is None and dim == 2 and hasattr(be, "kinetic_potential_vjp") and getattr(be, "_tables_ok", False)
+          and getattr(be, "_pwl_mode", 0) != 0 and count >= TABLE_BACKWARD_MIN_SLICE
+          and count * n_slices * passes >= TABLE_BACKWARD_MIN_POINTS)
+
+
 def _neg_logprob_tables(ctx, samples, cond, coef):
   """-sum log_prob(samples; cond) and its gradient: data -> base pass, log_prob = base(x) + ildj."""
   be = ctx.be
   c = be.slice_conds([cond])
   # value and gradient from ONE launch over the data (cnf_neg_logprob_vjp: the backward kernel seeds itself)
-  total = be.neg_logprob_vjp(samples, c, coef, ctx.grad)
+  total = be.neg_logprob_vjp(samples, c, coef, ctx.grad) if ctx.grad is not None else None
   if total is not None:
     return total
   # plain fp32 positions, like the fused loss kernel: a mean over the batch does not need the float64 position path
@@ -341,8 +350,10 @@ def _neg_logprob_tables(ctx, samples, cond, coef):
   finally:
     be.set_precise(was)
   # d(-sum lp) scaled by coef: lp_bar = -coef; x_bar = lp_bar * d base/dx = coef * x; ld_bar = -coef
-  total, xbar, ldbar = be.term_residual(_capi.TERM_NEG_LOGPROB, x, ildj, x.shape[0], loss_coef=coef)
-  be.pass_vjp(samples, c, xbar, ldbar, True, grad=ctx.grad, want_xbar=False)
+  total, xbar, ldbar = be.term_residual(_capi.TERM_NEG_LOGPROB, x, ildj, x.shape[0], loss_coef=coef,
+                                        want_adjoints=ctx.grad is not None)
+  if ctx.grad is not None:
+    be.pass_vjp(samples, c, xbar, ldbar, True, grad=ctx.grad, want_xbar=False)
   return total
 
 
@@ -358,8 +369,9 @@ def _kinetic_tables(ctx, z, conds, count, dt, coef):
     return done[0]
   z2 = z.repeat(2 * S, 1)
   r, _ = be.forward_logdet(z2, c2, want_logdet=False)
-  sums, rbar, _ = be.term_residual(_capi.TERM_KINETIC, r, None, count, p0=dt, loss_coef=coef)
-  be.pass_vjp(z2, c2, rbar, None, False, grad=ctx.grad, want_xbar=False)
+  sums, rbar, _ = be.term_residual(_capi.TERM_KINETIC, r, None, count, p0=dt, loss_coef=coef, want_adjoints=ctx.grad is not None)
+  if ctx.grad is not None:
+    be.pass_vjp(z2, c2, rbar, None, False, grad=ctx.grad, want_xbar=False)
   return sums
 
 
@@ -372,8 +384,9 @@ def _potential_tables(ctx, z, conds, count, subtype, a, coef):
   zr = z.repeat(S, 1) if S > 1 else z
   r, _ = be.forward_logdet(zr, c, want_logdet=False)
   sums, rbar, _ = be.term_residual(_capi.TERM_POTENTIAL, r, None, count, subtype=_capi.POTENTIALS[subtype], p0=a,
-                                   loss_coef=coef)
-  be.pass_vjp(zr, c, rbar, None, False, grad=ctx.grad, want_xbar=False)
+                                   loss_coef=coef, want_adjoints=ctx.grad is not None)
+  if ctx.grad is not None:
+    be.pass_vjp(zr, c, rbar, None, False, grad=ctx.grad, want_xbar=False)
   return sums
 
 
@@ -392,6 +405,11 @@ def _kinetic_potential_tables(ctx, z, conds, count, dt, c_kin, subtype, a, c_pot
     return done
   z3 = z.repeat(3 * S, 1)
   r, _ = be.forward_logdet(z3, c3, want_logdet=False)
+  if ctx.grad is None:
+    kin, _, _ = be.term_residual(_capi.TERM_KINETIC, r[:2 * n], None, count, p0=dt, loss_coef=c_kin, want_adjoints=False)
+    pot, _, _ = be.term_residual(_capi.TERM_POTENTIAL, r[2 * n:], None, count, subtype=_capi.POTENTIALS[subtype], p0=a,
+                                 loss_coef=c_pot, want_adjoints=False)
+    return kin, pot
   rbar = torch.empty_like(r)
   kin, _, _ = be.term_residual(_capi.TERM_KINETIC, r[:2 * n], None, count, p0=dt, loss_coef=c_kin, rbar_out=rbar[:2 * n])
   pot, _, _ = be.term_residual(_capi.TERM_POTENTIAL, r[2 * n:], None, count, subtype=_capi.POTENTIALS[subtype], p0=a,
@@ -412,7 +430,7 @@ def _kl_sum(ctx, T, cond, batch_size, source, coef):
     samples = z
   else:
     samples = s1 * ((T - cond) / T) + z * (cond / T)      # target N(0,I) drawn from the same key
-  if _use_table_backward(ctx, z.shape[1], count, 1):
+  if _use_table_backward(ctx, z.shape[1], count, 1) or _use_table_values(ctx, z.shape[1], count, 1):
     return _neg_logprob_tables(ctx, samples.contiguous(), cond, coef)
   return ctx.terms(_spec(_capi.TERM_NEG_LOGPROB), samples.contiguous(), [cond], count, coef)
 
@@ -428,14 +446,15 @@ def _potential_sum(ctx, a, subtype, conds, batch_size, coef):
   if subtype not in _capi.POTENTIALS:
     raise ValueError(f"unknown potential {subtype!r}")
   z, _, count = ctx.noise(batch_size)
-  if _use_table_backward(ctx, z.shape[1], count, _n_conds(conds)):
+  if _use_table_backward(ctx, z.shape[1], count, _n_conds(conds)) or _use_table_values(ctx, z.shape[1], count, _n_conds(conds)):
     return _potential_tables(ctx, z, conds, count, subtype, a, coef)
   return ctx.terms(_spec(_capi.TERM_POTENTIAL, subtype=_capi.POTENTIALS[subtype], a=a), z, conds, count, coef)
 
 
 def _kinetic_sum(ctx, dt, conds, batch_size, coef):
   z, _, count = ctx.noise(batch_size)
-  if _use_table_backward(ctx, z.shape[1], count, _n_conds(conds), passes=2):
+  if (_use_table_backward(ctx, z.shape[1], count, _n_conds(conds), passes=2)
+      or _use_table_values(ctx, z.shape[1], count, _n_conds(conds), passes=2)):
     return _kinetic_tables(ctx, z, conds, count, dt, coef)
   return ctx.terms(_spec(_capi.TERM_KINETIC, dt=dt), z, conds, count, coef)
 
@@ -603,7 +622,8 @@ def ot_loss_fn(model, dim, T, dt, t_batch_size, subtype, params, rng, _lambda, b
   def later():
     if subtype == "obstacle":      # summed, not averaged, over slices (applications.py:397-400)
       z, _, count = ctx.noise(sub)
-      if _use_table_backward(ctx, z.shape[1], count, _n_conds(t_batch), passes=2):      # one forward + one backward launch for both
+      if (_use_table_backward(ctx, z.shape[1], count, _n_conds(t_batch), passes=2)      # one forward + one backward launch for both
+          or _use_table_values(ctx, z.shape[1], count, _n_conds(t_batch), passes=2)):
         return list(_kinetic_potential_tables(ctx, z, t_batch, count, dt, c_kin, "obstacle", 0.0, 1.0 / sub))
       return [_kinetic_sum(ctx, dt, t_batch, sub, c_kin), _potential_sum(ctx, 0.0, "obstacle", t_batch, sub, 1.0 / sub)]
     return [_kinetic_sum(ctx, dt, t_batch, sub, c_kin)]

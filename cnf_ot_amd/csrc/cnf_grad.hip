@@ -1931,14 +1931,14 @@ extern "C" int cnf_input_vjp(CnfModel* m, int to_base, const float* pts, const f
 extern "C" int cnf_kinetic_potential_vjp(CnfModel* m, const float* z, int64_t count, const float* c, int32_t S, float dt,
                                          float c_kin, int32_t subtype, float pot_a, float c_pot, double* kin,
                                          double* pot, float* grad, const float* params, float* work, void* stream_) {
-  if (!m || !z || !c || !kin || !grad || !params || !work || count < 1 || S < 1 || !(dt > 0.f)) return CNF_ERR_INVALID;
+  if (!m || !z || !c || !kin || (grad && !params) || !work || count < 1 || S < 1 || !(dt > 0.f)) return CNF_ERR_INVALID;
   if ((subtype >= 0) != (pot != nullptr)) return CNF_ERR_INVALID;
-  if (!m->params_set || !m->grad_slabs) return CNF_ERR_INVALID;
-  {      // (pass_vjp_pwl's conditions, asked before anything is launched)
+  if (!m->params_set || (grad && !m->grad_slabs)) return CNF_ERR_INVALID;
+  {      // (pass_vjp_pwl's conditions, asked before anything is launched; grad == NULL: the terms' values alone)
     const CnfConfig& g = m->cfg;
-    if (!cnf_grad_supported(&g) || !m->use_pwl || !m->fast_math || !m->pwl_stats || g.dim != 2 || g.hidden_size != PWL_H ||
-        g.num_bins != GK || g.mlp_num_layers != 2 || g.num_layers > 4 || g.periodized)
+    if (!m->use_pwl || g.dim != 2 || g.hidden_size != PWL_H || g.num_bins != GK || g.mlp_num_layers != 2 || g.periodized)
       return CNF_ERR_UNSUPPORTED;
+    if (grad && (!cnf_grad_supported(&g) || !m->fast_math || !m->pwl_stats || g.num_layers > 4)) return CNF_ERR_UNSUPPORTED;
   }
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t sets = pot ? 3 : 2, ns = sets * S, B = ns * count, n = (int64_t)S * count;
@@ -1946,13 +1946,13 @@ extern "C" int cnf_kinetic_potential_vjp(CnfModel* m, const float* z, int64_t co
   if (m->use_pwl == 1 && (count < 8192 || B < 262144)) return CNF_ERR_UNSUPPORTED;      // (pass_vjp_pwl's thresholds)
   if (wait_for_params(m, stream) != CNF_OK) return CNF_ERR_HIP;
   float* r = work;
-  float* rbar = work + 2 * B;
+  float* rbar = grad ? work + 2 * B : nullptr;
   float* tables = nullptr;
   int rc = cnf_internal_build_tables(m, stream, c, ns, &tables);
   if (rc != CNF_OK) return rc;
   rc = cnf_internal_flow_shared(m, stream, z, c, count, ns, tables, r);
   if (rc != CNF_OK) return rc;                                   // (UNSUPPORTED: nothing but the tables was touched)
-  uint32_t* amax = reinterpret_cast<uint32_t*>(m->pwl_stats);    // zero on entry (pass_vjp_pwl)
+  uint32_t* amax = grad ? reinterpret_cast<uint32_t*>(m->pwl_stats) : nullptr;    // zero on entry (pass_vjp_pwl)
   if (hipMemsetAsync(kin, 0, sizeof(double) * (size_t)S, stream) != hipSuccess) return CNF_ERR_HIP;
   if (pot && hipMemsetAsync(pot, 0, sizeof(double) * (size_t)S, stream) != hipSuccess) return CNF_ERR_HIP;
   TermResidArgs a;
@@ -1961,11 +1961,12 @@ extern "C" int cnf_kinetic_potential_vjp(CnfModel* m, const float* z, int64_t co
   a.r = r; a.rbar = rbar; a.sums = kin; a.kind = CNF_TERM_KINETIC; a.subtype = 0; a.p0 = dt; a.loss_coef = c_kin;
   hipLaunchKernelGGL(term_residual_kernel<2>, dim3((unsigned)blocks), dim3(1024), 0, stream, a);
   if (pot) {
-    a.r = r + 4 * n; a.rbar = rbar + 4 * n; a.sums = pot; a.kind = CNF_TERM_POTENTIAL; a.subtype = subtype; a.p0 = pot_a;
+    a.r = r + 4 * n; a.rbar = rbar ? rbar + 4 * n : nullptr; a.sums = pot; a.kind = CNF_TERM_POTENTIAL; a.subtype = subtype; a.p0 = pot_a;
     a.loss_coef = c_pot;
     hipLaunchKernelGGL(term_residual_kernel<2>, dim3((unsigned)blocks), dim3(1024), 0, stream, a);
   }
   if (hipGetLastError() != hipSuccess) return CNF_ERR_HIP;
+  if (!grad) return CNF_OK;
   rc = pass_vjp_pwl(m, 0, z, c, count, rbar, nullptr, nullptr, grad, params, B, stream, 0.0f, nullptr, tables);
   if (rc != CNF_OK) {      // the adjoint maximum was left behind for a backward that did not run
     (void)hipMemsetAsync(amax, 0, 8, stream);

@@ -572,8 +572,8 @@ class FlowEngine:
   def kinetic_potential_vjp(self, z, conds, S: int, dt: float, c_kin: float, grad, subtype: int = -1, a: float = 0.0,
                             c_pot: float = 0.0, kin=None, pot=None):
     """cnf_kinetic_potential_vjp: per-time sums of the kinetic (and, subtype >= 0, the potential) term for the ONE
-    draw z [count, 2] pushed to the 2 S (3 S) conditions `conds`, and their gradient into `grad`.  Returns (kin, pot)
-    or None where the call does not apply (the caller composes the term from its parts)."""
+    draw z [count, 2] pushed to the 2 S (3 S) conditions `conds`, and their gradient into `grad` (None: the values
+    alone).  Returns (kin, pot) or None where the call does not apply (the caller composes the term from its parts)."""
     z = self._points(z, "kinetic_potential_vjp")
     count = z.shape[0]
     sets = 3 if subtype >= 0 else 2
@@ -583,13 +583,14 @@ class FlowEngine:
       raise ValueError(f"kinetic_potential_vjp: {sets * S} conditions expected, got {c.numel()}")
     if not self._pwl_mode or count == 0 or self.cfg.dim != 2:
       return None
-    if self._flat is None:
-      raise RuntimeError("load(params) before asking for gradients")
-    if not getattr(self, "_grad_enabled", False):
-      with _OnDevice(self.device):
-        _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
-      self._grad_enabled = True
-    self._check_out(grad, (self.cfg.param_count(),), "grad")
+    if grad is not None:
+      if self._flat is None:
+        raise RuntimeError("load(params) before asking for gradients")
+      if not getattr(self, "_grad_enabled", False):
+        with _OnDevice(self.device):
+          _capi.check(self.lib.cnf_grad_enable(self._h, 0), "cnf_grad_enable")
+        self._grad_enabled = True
+      self._check_out(grad, (self.cfg.param_count(),), "grad")
     if sets * S > 128:
       return None
     self.reserve(sets * S)
@@ -603,8 +604,10 @@ class FlowEngine:
     with _OnDevice(self.device):
       rc = self.lib.cnf_kinetic_potential_vjp(self._h, z.data_ptr(), count, c.data_ptr(), int(S), float(dt), float(c_kin),
                                               int(subtype), float(a), float(c_pot), kin.data_ptr(),
-                                              pot.data_ptr() if subtype >= 0 else None, grad.data_ptr(),
-                                              self._flat.data_ptr(), work.data_ptr(), _stream_ptr(self.device))
+                                              pot.data_ptr() if subtype >= 0 else None,
+                                              grad.data_ptr() if grad is not None else None,
+                                              self._flat.data_ptr() if grad is not None else None, work.data_ptr(),
+                                              _stream_ptr(self.device))
     if rc == _capi.CNF_ERR_UNSUPPORTED:
       return None
     _capi.check(rc, "cnf_kinetic_potential_vjp")

@@ -367,7 +367,8 @@ int cnf_neg_logprob_vjp(CnfModel *m, const float *pts, const float *c,
  * launch in which all slices read the same z (no repeated copy of it), the term epilogues, which also leave the largest
  * adjoint for the backward (no scan), and one backward launch -- what cnf_sample + cnf_term_residual + cnf_pass_vjp do
  * in six launches over 2 (3) S repeated copies of z.  work: 4 x 2 (3) S x count floats, 16-byte aligned (the pushed
- * points and their adjoints).  pot == NULL iff subtype < 0.  CNF_ERR_UNSUPPORTED (nothing written) where the table
+ * points and their adjoints).  pot == NULL iff subtype < 0.  grad == NULL: the terms' values alone (the loss without
+ * jax.value_and_grad; work: 2 x 2 (3) S x count floats).  CNF_ERR_UNSUPPORTED (nothing written) where the table
  * backward does not apply or 2 (3) S > 128: compose the term from those calls. */
 int cnf_kinetic_potential_vjp(CnfModel *m, const float *z, int64_t count,
                               const float *c, int32_t S, float dt, float c_kin,

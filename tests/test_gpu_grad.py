@@ -597,6 +597,35 @@ def test_value_and_grad_through_the_table_backward(dev, subtype, monkeypatch):
   assert el <= 2e-5 and eg <= 2e-4
 
 
+@pytest.mark.parametrize("subtype", ["free", "obstacle"])
+def test_loss_without_gradient_through_the_tables(dev, subtype, monkeypatch):
+  """ot_loss_fn WITHOUT a gradient at a large dim-2 batch (forced here): its terms composed from the table forward and
+  the term epilogues (cnf_kinetic_potential_vjp with grad = NULL; cnf_inverse_logdet + cnf_term_residual) -- the same
+  loss as the fused loss kernel, and as the value the gradient path returns."""
+  from cnf_ot_amd import RQSFlow, Params, applications as app
+  model = RQSFlow(event_shape=(2,), num_layers=2, hidden_sizes=[16, 16], num_bins=5)
+  params = Params.random(model.cfg, 0.15, seed=9, device=dev)
+  B, tbs = 65536, 3
+  f = lambda p, rng, lam, bs, **kw: app.ot_loss_fn(model, 2, 1.0, 0.01, tbs, subtype, p, rng, lam, bs, source="gaussian", **kw)
+  be = model.terms_backend(params)
+  be.set_pwl(0)
+  loss0 = float(f(params, 11, 50.0, B))
+  used = []
+  monkeypatch.setattr(app, "TABLE_BACKWARD_MIN_SLICE", 256)
+  monkeypatch.setattr(app, "TABLE_BACKWARD_MIN_POINTS", 256)
+  orig_kp = be.kinetic_potential_vjp
+  monkeypatch.setattr(be, "kinetic_potential_vjp", lambda *a, **k: (used.append(a[5] is None), orig_kp(*a, **k))[1])
+  be.set_pwl(2)
+  loss2 = float(f(params, 11, 50.0, B))
+  lossg, _ = app.value_and_grad(f)(params, 11, 50.0, B)
+  torch.cuda.synchronize()
+  be.set_pwl(1)
+  assert used == [True, False]      # values alone, then with the gradient
+  e0, eg = abs(loss2 - loss0) / abs(loss0), abs(loss2 - float(lossg)) / abs(loss0)
+  print(f"\n[ot {subtype}: loss on the tables vs fused kernel] rel {e0:.2e}; vs the gradient path's value {eg:.2e}")
+  assert e0 <= 2e-5 and eg <= 1e-6
+
+
 def test_fused_term_calls_decline_flag_and_recover(dev):
   """cnf_neg_logprob_vjp / cnf_kinetic_potential_vjp at their edges: below the table backward's thresholds (default
   table mode) and past 128 slices they decline (None: the caller composes the term) and leave the gradient untouched;
