@@ -1,12 +1,12 @@
 #!/bin/bash
-# rocprofv3 kernel trace + stats of one BASELINE config's value_and_grad only: scripts/gpu_trace_cfg.sh cfg5 r03g
-CFG=${1:-cfg5}; TAG=${2:-r03}; REPS=${3:-20}
+# rocprofv3 kernel trace + stats of one BASELINE config's value_and_grad (or loss) only: scripts/gpu_trace_cfg.sh cfg5 r03g [reps] [vg|loss]
+CFG=${1:-cfg5}; TAG=${2:-r03}; REPS=${3:-20}; WHAT=${4:-vg}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/trace_${TAG}_$CFG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/scripts/prof_cfg.py $CFG $REPS vg > $OUT/trace.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/scripts/prof_cfg.py $CFG $REPS $WHAT > $OUT/trace.log 2>&1
 rc=$?; echo "trace rc=$rc"; tail -2 $OUT/trace.log
 f=$(find $OUT/trace -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && python3 - $OUT/kernel_stats.csv $REPS <<'PY'

@@ -9,14 +9,14 @@ from cnf_ot_amd import applications as app
 
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-only = sys.argv[3] if len(sys.argv) > 3 else ""   # "vg": value_and_grad alone (a kernel trace of just that)
+only = sys.argv[3] if len(sys.argv) > 3 else ""   # "vg" / "loss": that one alone (a kernel trace of just it)
 dev = torch.device("cuda", 0)
 step, f, params, B, passes, desc = bench._config_steps(dev, which)
 share = 8 if which in ("cfg4", "cfg5") else 1
 Bl = B // share
 vg = app.value_and_grad(f)
 for fn, name in ((lambda: f(params, 42, 5000.0, Bl), "loss"), (lambda: vg(params, 42, 5000.0, Bl), "value_and_grad")):
-  if only == "vg" and name == "loss":
+  if (only == "vg" and name == "loss") or (only == "loss" and name != "loss"):
     continue
   fn(); torch.cuda.synchronize()
   t0 = time.perf_counter()
