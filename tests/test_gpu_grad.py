@@ -669,14 +669,15 @@ def test_fused_term_calls_decline_flag_and_recover(dev):
   eng.set_pwl(1)
 
 
+@pytest.mark.parametrize("L", [2, 3])
 @pytest.mark.parametrize("subtype", [None, "obstacle", "double_well"])
 @pytest.mark.parametrize("S,count", [(1, 70002), (5, 9000), (32, 8194)])
-def test_kinetic_potential_vjp_equals_the_composed_terms(dev, subtype, S, count):
+def test_kinetic_potential_vjp_equals_the_composed_terms(dev, subtype, S, count, L):
   """cnf_kinetic_potential_vjp (kinetic_loss_fn + potential_loss_fn as ot_loss_fn combines them, applications.py:176-242,
   388-402, under jax.value_and_grad) against the same terms composed from cnf_sample on repeated copies of z +
   cnf_term_residual + cnf_pass_vjp: the same tables, kernels and adjoints, so sums to 1e-12 and the gradient BIT FOR BIT."""
   from cnf_ot_amd import FlowConfig, FlowEngine, Params, _capi
-  cfg = FlowConfig(dim=2)
+  cfg = FlowConfig(dim=2, num_layers=L)
   params = Params.random(cfg, 0.2, seed=4, device=dev)
   eng = FlowEngine(cfg, dev).load(params)
   eng.set_pwl(2)
@@ -708,6 +709,12 @@ def test_kinetic_potential_vjp_equals_the_composed_terms(dev, subtype, S, count)
   else:
     assert pot1 is None
   assert torch.equal(g1, g0)
+  # grad = None: the values alone, the same sums
+  out = eng.kinetic_potential_vjp(z, c, S, dt, c_kin, None, subtype=_capi.POTENTIALS[subtype] if subtype else -1, a=a, c_pot=c_pot)
+  torch.cuda.synchronize()
+  torch.testing.assert_close(out[0], kin0, rtol=1e-12, atol=0)
+  if subtype:
+    torch.testing.assert_close(out[1], pot0, rtol=1e-12, atol=0)
 
 
 @pytest.mark.parametrize("L", [2, 3])
