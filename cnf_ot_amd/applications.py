@@ -170,7 +170,9 @@ class _Ctx:
     rep = []
     for _, c, count, _, _ in passes:
       if dev:
-        c = c if torch.is_tensor(c) else torch.from_numpy(np.ascontiguousarray(c)).to(be.device)
+        # (the cached upload of slice_conds: a fresh host-to-device copy is not permitted inside a graph capture -- the
+        # captured step failed from dim 6 up, where the reverse-KL pass [cond 0] is merged with the score term's)
+        c = c if torch.is_tensor(c) else be.slice_conds(c)
         rep.append(c.repeat_interleave(count // g))
       else:
         rep.append(np.repeat(c, count // g))

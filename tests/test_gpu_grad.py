@@ -257,7 +257,7 @@ def test_adam_step_and_training_decreases_loss(dev):
   assert np.isfinite(last) and last < first
 
 
-@pytest.mark.parametrize("kind", ["ot", "rwpo", "ot_large"])
+@pytest.mark.parametrize("kind", ["ot", "rwpo", "ot_large", "rwpo_dim6", "fp_dim6"])
 def test_captured_step_equals_the_eager_step_bit_for_bit(dev, kind):
   """solvers.CapturedUpdate: `update` (solvers.py:90-97) captured into one HIP graph -- key, time batch, mixture
   components, base noise and Adam's step count all read from device memory -- against the very same body run
@@ -268,6 +268,9 @@ def test_captured_step_equals_the_eager_step_bit_for_bit(dev, kind):
   if kind == "ot_large":      # a batch whose terms run as the fused table-backward calls (cnf_neg_logprob_vjp, cnf_kinetic_potential_vjp)
     kind, B = "ot", 1 << 21
   ov = {"general": {"type": kind, "t_batch_size": 8 if B > 2048 else 2}, "train": {"batch_size": B, "lr": 1e-3}}
+  if kind.endswith("_dim6"):      # the score terms from separate launches (applications._score_terms_unfused) inside the graph
+    ov["general"].update(type=kind[:-5], dim=6)
+    ov["fp"] = {"velocity_field_type": "ou"}
   config = solvers.load_config(overrides=ov)
   res = []
   for replay in (False, True):
